@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI declared in include/vsn.h (libvsn_hip.so).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to
+load, importing the product path raises.  (The CPU restatement under oracle/
+is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvsn_hip.so")
+
+
+class VsnHParams(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32),
+        ("num_layers", C.c_int32),
+        ("num_rbf", C.c_int32),
+        ("num_heads", C.c_int32),
+        ("lmax", C.c_int32),
+        ("max_z", C.c_int32),
+        ("max_num_neighbors", C.c_int32),
+        ("vecnorm_type", C.c_int32),
+        ("has_atomref", C.c_int32),
+        ("cutoff", C.c_float),
+    ]
+
+
+VECNORM = {"none": 0, "rms": 1, "max_min": 2}
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the MI355X ViSNet calculator needs its HIP extension "
+            "(build it with `python -m ai2bmd_amd.build`); there is no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i64p, f32p = C.c_void_p, C.POINTER(C.c_int64), C.c_void_p
+    L.vsn_create.argtypes = [C.POINTER(vp), C.POINTER(VsnHParams), C.c_int]
+    L.vsn_create.restype = C.c_int
+    L.vsn_destroy.argtypes = [vp]
+    L.vsn_destroy.restype = None
+    L.vsn_last_error.argtypes = [vp]
+    L.vsn_last_error.restype = C.c_char_p
+    L.vsn_load_weight.argtypes = [vp, C.c_char_p, vp, i64p, C.c_int]
+    L.vsn_load_weight.restype = C.c_int
+    L.vsn_finalize.argtypes = [vp]
+    L.vsn_finalize.restype = C.c_int
+    L.vsn_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.vsn_set_option.restype = C.c_int
+    L.vsn_forces.argtypes = [vp, vp, f32p, i64p, i64p, C.c_int64, C.c_int64, f32p, f32p, vp]
+    L.vsn_forces.restype = C.c_int
+    L.vsn_last_num_edges.argtypes = [vp]
+    L.vsn_last_num_edges.restype = C.c_int64
+    L.vsn_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
+    L.vsn_debug_read.restype = C.c_int64
+    L.vsn_gemm.argtypes = [vp, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int,
+                           C.c_int, vp]
+    L.vsn_gemm.restype = C.c_int
+    L.vsn_combine_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int64, C.c_int64, C.c_int64, i64p, i64p,
+                                          i64p, C.c_int64]
+    L.vsn_combine_plan_create.restype = C.c_int
+    L.vsn_combine_plan_destroy.argtypes = [vp]
+    L.vsn_combine_plan_destroy.restype = None
+    L.vsn_combine.argtypes = [vp, f32p, f32p, vp]
+    L.vsn_combine.restype = C.c_int
+    L.vsn_partition.argtypes = [i64p, i64p, C.c_int64, C.c_int, C.c_int64, i64p, C.c_int]
+    L.vsn_partition.restype = C.c_int
+    _lib = L
+    return L
+
+
+def i64_ptr(a):
+    """numpy int64 C-contiguous array -> POINTER(c_int64)"""
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+EXPORTS = [
+    "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
+    "vsn_forces", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
+    "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition",
+]

@@ -1,0 +1,76 @@
+// Shared device helpers for the gfx950 ViSNet kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VSN_WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- activations (silu == swish; reference utils.py:110-116) ---------------
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = sigmoid_f(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ void silu_both(float x, float& y, float& dy) {
+  float s = sigmoid_f(x);
+  y = x * s;
+  dy = s * (1.0f + x * (1.0f - s));
+}
+
+// ---- wave64 reductions -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over aligned groups of `width` consecutive lanes (width power of two)
+__device__ __forceinline__ float group_sum(float v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- per-lane row fragments: a row of H = 64*V floats, lane owns V contiguous --
+template <int V>
+struct RowVec;
+template <>
+struct RowVec<1> {
+  typedef float T;
+};
+template <>
+struct RowVec<2> {
+  typedef float2 T;
+};
+template <>
+struct RowVec<4> {
+  typedef float4 T;
+};
+
+template <int V>
+__device__ __forceinline__ void ldrow(const float* __restrict__ row, int lane, float (&r)[V]) {
+  typedef typename RowVec<V>::T T;
+  T t = *reinterpret_cast<const T*>(row + lane * V);
+  const float* p = reinterpret_cast<const float*>(&t);
+#pragma unroll
+  for (int i = 0; i < V; ++i) r[i] = p[i];
+}
+template <int V>
+__device__ __forceinline__ void strow(float* __restrict__ row, int lane, const float (&r)[V]) {
+  typedef typename RowVec<V>::T T;
+  T t;
+  float* p = reinterpret_cast<float*>(&t);
+#pragma unroll
+  for (int i = 0; i < V; ++i) p[i] = r[i];
+  *reinterpret_cast<T*>(row + lane * V) = t;
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// one wave per node, grid-strided
+#define VSN_NODE_LOOP(node, N)                                        \
+  const int lane = threadIdx.x & 63;                                  \
+  const int wv__ = threadIdx.x >> 6, nwv__ = blockDim.x >> 6;         \
+  for (int node = blockIdx.x * nwv__ + wv__; node < (N); node += gridDim.x * nwv__)

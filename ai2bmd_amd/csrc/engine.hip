@@ -1,0 +1,975 @@
+// Host-side engine + C ABI (include/vsn.h) of the MI355X ViSNet calculator.
+//
+// Owns: packed weights (fused / padded / pre-transposed for the reverse pass),
+// the per-chunk workspace arena, and the launch sequence of one energy+force
+// evaluation (graph -> embeddings -> L x ViS-MP -> read-out -> hand-written
+// reverse pass -> forces).  Replaces the TorchScript module + autograd the
+// reference runs in ViSNetModel.dl_potential_loader
+// (/root/reference/src/Calculators/visnet_calculator.py:54-63,
+//  /root/reference/src/ViSNet/model/visnet.py:135-166).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vsn.h"
+#include "kernels.h"
+
+using namespace vsn;
+
+#define VSN_MAX_FRAG_ATOMS 16000
+
+namespace {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+struct LayerW {
+  float *Wqkv, *bqkv, *WqkvT;
+  float *Wv5, *Wv5T;
+  float *We3, *be3, *We3T;
+  float *Ws, *bs, *WsT;
+  float *Wo, *bo, *WoT;
+  float *ln_g, *ln_b, *vln_w;
+};
+
+struct LayerBuf {
+  float *xn, *rstd, *vh, *qkv, *vp, *pe, *tpre, *o;
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  bool dry = true;
+  template <typename T>
+  T* take(size_t n) {
+    size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += bytes;
+    return p;
+  }
+};
+
+}  // namespace
+
+struct vsn_ctx {
+  vsn_hparams hp;
+  int device = 0;
+  std::string err;
+  std::map<std::string, HostTensor> raw;
+  bool finalized = false;
+  int H = 0, L = 0, R = 0, Rp = 0, S = 0, nh = 0, Z = 0;
+  // packed weights
+  float* warena = nullptr;
+  float *emb1, *emb2, *means, *betas, *Wrbf, *brbf, *WrbfT, *Wc, *bc, *WcnT, *on_g, *on_b, *vo_w;
+  std::vector<LayerW> lw;
+  HeadW hw;
+  float* d_atomref = nullptr;
+  // workspace
+  Arena ws;
+  int capN = 0, capE = 0, capB = 0;
+  bool debug = false;
+  int64_t max_chunk_edges = 262144;
+  // buffers
+  int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
+  float *geo, *d, *rbf, *drbf;
+  float *pp, *cat, *x_emb, *x, *vec, *f;
+  std::vector<LayerBuf> lb;
+  float *xh, *m, *A;
+  float *xn_o, *rstd_o, *vo;
+  HeadBuf hb;
+  float* g_vo;
+  float *g_x, *g_vec, *g_f;
+  float *g_o, *g_vp, *g_A, *g_t, *g_m, *g_pe, *g_qkv, *g_vh, *g_xh, *sat_tmp;
+  float *g_pp, *g_n, *g_rbf, *g_geo, *g_ev;
+  // debug snapshots: name -> per-layer device copies
+  std::map<std::string, std::vector<float*>> snap;
+  std::map<std::string, size_t> snap_elems;
+  // last chunk dims
+  int lastN = 0, lastB = 0, lastEmax = 0;
+  std::vector<int> h_fs, h_fe;
+};
+
+static int fail(vsn_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                          \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return fail(c, -5, std::string(#call) + ": " + hipGetErrorString(e__));                    \
+  } while (0)
+
+extern "C" int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id) {
+  if (!out || !hp) return -22;
+  vsn_ctx* c = new vsn_ctx();
+  c->hp = *hp;
+  c->device = device_id;
+  c->H = hp->hidden;
+  c->L = hp->num_layers;
+  c->R = hp->num_rbf;
+  c->Rp = (hp->num_rbf + 31) / 32 * 32;
+  c->S = (hp->lmax + 1) * (hp->lmax + 1) - 1;
+  c->nh = hp->num_heads;
+  c->Z = hp->max_z;
+  *out = c;
+  if (!(c->H == 64 || c->H == 128 || c->H == 256)) return fail(c, -22, "hidden must be 64, 128 or 256");
+  if (!(hp->lmax == 1 || hp->lmax == 2)) return fail(c, -22, "lmax must be 1 or 2");
+  if (c->nh <= 0 || c->nh > 64 || (c->nh & (c->nh - 1)) || (c->H % c->nh))
+    return fail(c, -22, "num_heads must be a power of two <= 64 dividing hidden");
+  if ((c->H / c->nh) % (c->H / 64)) return fail(c, -22, "head_dim must be a multiple of hidden/64");
+  if (c->L < 1) return fail(c, -22, "num_layers must be >= 1");
+  if (hp->vecnorm_type != VSN_VECNORM_NONE)
+    return fail(c, -38, "vecnorm_type rms/max_min not built yet in the HIP path");
+  if (hipSetDevice(device_id) != hipSuccess) return fail(c, -19, "hipSetDevice failed (no MI355X visible?)");
+  return 0;
+}
+
+extern "C" void vsn_destroy(vsn_handle c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->warena) hipFree(c->warena);
+  if (c->ws.base) hipFree(c->ws.base);
+  for (auto& kv : c->snap)
+    for (float* p : kv.second)
+      if (p) hipFree(p);
+  delete c;
+}
+
+extern "C" const char* vsn_last_error(vsn_handle c) { return c ? c->err.c_str() : "null handle"; }
+
+extern "C" int vsn_load_weight(vsn_handle c, const char* name, const void* ptr, const int64_t* shape, int ndim) {
+  if (!c || !name || !ptr) return -22;
+  HIPCHK(c, hipSetDevice(c->device));
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    t.shape.push_back(shape[i]);
+    n *= (size_t)shape[i];
+  }
+  t.data.resize(n);
+  HIPCHK(c, hipMemcpy(t.data.data(), ptr, n * sizeof(float), hipMemcpyDefault));
+  c->raw[name] = std::move(t);
+  c->finalized = false;
+  return 0;
+}
+
+extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
+  if (!c || !key) return -22;
+  std::string k(key);
+  if (k == "max_chunk_edges") {
+    if (value < 1024) return fail(c, -22, "max_chunk_edges too small");
+    c->max_chunk_edges = value;
+  } else if (k == "debug") {
+    c->debug = value != 0;
+  } else {
+    return fail(c, -22, "unknown option " + k);
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------
+namespace {
+struct Packer {
+  std::vector<float> host;
+  size_t add(const std::vector<float>& v) {
+    size_t off = host.size();
+    host.insert(host.end(), v.begin(), v.end());
+    while (host.size() % 64) host.push_back(0.f);  // 256-byte alignment
+    return off;
+  }
+};
+std::vector<float> transposed(const std::vector<float>& w, int rows, int cols) {
+  std::vector<float> t((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int cidx = 0; cidx < cols; ++cidx) t[(size_t)cidx * rows + r] = w[(size_t)r * cols + cidx];
+  return t;
+}
+std::vector<float> vcat(std::initializer_list<const std::vector<float>*> parts) {
+  std::vector<float> o;
+  for (auto* p : parts) o.insert(o.end(), p->begin(), p->end());
+  return o;
+}
+}  // namespace
+
+static const std::vector<float>* need(vsn_ctx* c, const std::string& name, size_t elems, std::string& missing) {
+  auto it = c->raw.find(name);
+  if (it == c->raw.end()) {
+    missing = "missing tensor " + name;
+    return nullptr;
+  }
+  if (it->second.data.size() != elems) {
+    missing = "tensor " + name + " has " + std::to_string(it->second.data.size()) + " elements, expected " +
+              std::to_string(elems);
+    return nullptr;
+  }
+  return &it->second.data;
+}
+
+extern "C" int vsn_finalize(vsn_handle c) {
+  if (!c) return -22;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int H = c->H, L = c->L, R = c->R, Rp = c->Rp, Z = c->Z, h2 = H / 2;
+  std::string miss;
+  Packer P;
+  const std::string rm = "representation_model.";
+#define NEED(var, name, elems)                              \
+  const std::vector<float>* var = need(c, name, elems, miss); \
+  if (!var) return fail(c, -2, miss);
+
+  NEED(emb1, rm + "embedding.weight", (size_t)Z * H);
+  NEED(means, rm + "distance_expansion.means", (size_t)R);
+  NEED(betas, rm + "distance_expansion.betas", (size_t)R);
+  NEED(emb2, rm + "neighbor_embedding.embedding.weight", (size_t)Z * H);
+  NEED(Wd, rm + "neighbor_embedding.distance_proj.weight", (size_t)H * R);
+  NEED(bd, rm + "neighbor_embedding.distance_proj.bias", (size_t)H);
+  NEED(Wc, rm + "neighbor_embedding.combine.weight", (size_t)H * 2 * H);
+  NEED(bc, rm + "neighbor_embedding.combine.bias", (size_t)H);
+  NEED(We, rm + "edge_embedding.edge_proj.weight", (size_t)H * R);
+  NEED(be, rm + "edge_embedding.edge_proj.bias", (size_t)H);
+  NEED(on_g, rm + "out_norm.weight", (size_t)H);
+  NEED(on_b, rm + "out_norm.bias", (size_t)H);
+  NEED(vo_w, rm + "vec_out_norm.weight", (size_t)H);
+  NEED(meanv, "mean", 1);
+  NEED(stdv, "std", 1);
+
+  std::map<std::string, size_t> off;
+  off["emb1"] = P.add(*emb1);
+  off["emb2"] = P.add(*emb2);
+  {
+    std::vector<float> m(Rp, 0.f), b(Rp, 0.f);
+    std::copy(means->begin(), means->end(), m.begin());
+    std::copy(betas->begin(), betas->end(), b.begin());
+    off["means"] = P.add(m);
+    off["betas"] = P.add(b);
+  }
+  {
+    // Wrbf [2H, Rp]: rows 0..H-1 distance_proj (phi), rows H..2H-1 edge_proj (psi); K zero-padded
+    std::vector<float> W((size_t)2 * H * Rp, 0.f), b(2 * H);
+    for (int r = 0; r < H; ++r)
+      for (int k = 0; k < R; ++k) {
+        W[(size_t)r * Rp + k] = (*Wd)[(size_t)r * R + k];
+        W[(size_t)(H + r) * Rp + k] = (*We)[(size_t)r * R + k];
+      }
+    for (int r = 0; r < H; ++r) {
+      b[r] = (*bd)[r];
+      b[H + r] = (*be)[r];
+    }
+    off["Wrbf"] = P.add(W);
+    off["brbf"] = P.add(b);
+    off["WrbfT"] = P.add(transposed(W, 2 * H, Rp));
+  }
+  off["Wc"] = P.add(*Wc);
+  off["bc"] = P.add(*bc);
+  {
+    std::vector<float> t((size_t)H * H);  // WcnT[c][k] = Wc[k][H + c]
+    for (int k = 0; k < H; ++k)
+      for (int cc = 0; cc < H; ++cc) t[(size_t)cc * H + k] = (*Wc)[(size_t)k * 2 * H + H + cc];
+    off["WcnT"] = P.add(t);
+  }
+  off["on_g"] = P.add(*on_g);
+  off["on_b"] = P.add(*on_b);
+  off["vo_w"] = P.add(*vo_w);
+
+  std::vector<std::map<std::string, size_t>> loff(L);
+  for (int l = 0; l < L; ++l) {
+    const bool last = (l == L - 1);
+    const std::string p = rm + "vis_mp_layers." + std::to_string(l) + ".";
+    NEED(lg, p + "layernorm.weight", (size_t)H);
+    NEED(lbias, p + "layernorm.bias", (size_t)H);
+    NEED(vw, p + "vec_layernorm.weight", (size_t)H);
+    NEED(Wvec, p + "vec_proj.weight", (size_t)3 * H * H);
+    NEED(Wq, p + "q_proj.weight", (size_t)H * H);
+    NEED(bq, p + "q_proj.bias", (size_t)H);
+    NEED(Wk, p + "k_proj.weight", (size_t)H * H);
+    NEED(bk, p + "k_proj.bias", (size_t)H);
+    NEED(Wv, p + "v_proj.weight", (size_t)H * H);
+    NEED(bv, p + "v_proj.bias", (size_t)H);
+    NEED(Wdk, p + "dk_proj.weight", (size_t)H * H);
+    NEED(bdk, p + "dk_proj.bias", (size_t)H);
+    NEED(Wdv, p + "dv_proj.weight", (size_t)H * H);
+    NEED(bdv, p + "dv_proj.bias", (size_t)H);
+    NEED(Wsp, p + "s_proj.weight", (size_t)2 * H * H);
+    NEED(bsp, p + "s_proj.bias", (size_t)2 * H);
+    NEED(Wop, p + "o_proj.weight", (size_t)3 * H * H);
+    NEED(bop, p + "o_proj.bias", (size_t)3 * H);
+    std::vector<float> zerosHH((size_t)H * H, 0.f), zerosH(H, 0.f);
+    const std::vector<float>*Wf = &zerosHH, *bf = &zerosH, *Wsrc = &zerosHH, *Wtrg = &zerosHH;
+    if (!last) {
+      NEED(Wf_, p + "f_proj.weight", (size_t)H * H);
+      NEED(bf_, p + "f_proj.bias", (size_t)H);
+      NEED(Wsrc_, p + "w_src_proj.weight", (size_t)H * H);
+      NEED(Wtrg_, p + "w_trg_proj.weight", (size_t)H * H);
+      Wf = Wf_;
+      bf = bf_;
+      Wsrc = Wsrc_;
+      Wtrg = Wtrg_;
+    }
+    auto& o = loff[l];
+    std::vector<float> Wqkv = vcat({Wq, Wk, Wv}), bqkv = vcat({bq, bk, bv});
+    o["Wqkv"] = P.add(Wqkv);
+    o["bqkv"] = P.add(bqkv);
+    o["WqkvT"] = P.add(transposed(Wqkv, 3 * H, H));
+    std::vector<float> Wv5 = vcat({Wvec, Wtrg, Wsrc});  // vec1|vec2|vec3|w_trg|w_src
+    o["Wv5"] = P.add(Wv5);
+    o["Wv5T"] = P.add(transposed(Wv5, 5 * H, H));
+    std::vector<float> We3 = vcat({Wdk, Wdv, Wf}), be3 = vcat({bdk, bdv, bf});
+    o["We3"] = P.add(We3);
+    o["be3"] = P.add(be3);
+    o["We3T"] = P.add(transposed(We3, 3 * H, H));
+    o["Ws"] = P.add(*Wsp);
+    o["bs"] = P.add(*bsp);
+    o["WsT"] = P.add(transposed(*Wsp, 2 * H, H));
+    o["Wo"] = P.add(*Wop);
+    o["bo"] = P.add(*bop);
+    o["WoT"] = P.add(transposed(*Wop, 3 * H, H));
+    o["ln_g"] = P.add(*lg);
+    o["ln_b"] = P.add(*lbias);
+    o["vln_w"] = P.add(*vw);
+  }
+  const std::string on = "output_model.output_network.";
+  NEED(W10, on + "0.vec1_proj.weight", (size_t)H * H);
+  NEED(W20, on + "0.vec2_proj.weight", (size_t)h2 * H);
+  NEED(Wa0, on + "0.update_net.0.weight", (size_t)H * 2 * H);
+  NEED(ba0, on + "0.update_net.0.bias", (size_t)H);
+  NEED(Wb0, on + "0.update_net.2.weight", (size_t)H * H);
+  NEED(bb0, on + "0.update_net.2.bias", (size_t)H);
+  NEED(W11, on + "1.vec1_proj.weight", (size_t)h2 * h2);
+  NEED(Wa1, on + "1.update_net.0.weight", (size_t)h2 * H);
+  NEED(ba1, on + "1.update_net.0.bias", (size_t)h2);
+  NEED(Wb1, on + "1.update_net.2.weight", (size_t)2 * h2);
+  NEED(bb1, on + "1.update_net.2.bias", (size_t)2);
+  std::vector<float> Wpv0 = vcat({W10, W20});
+  off["Wpv0"] = P.add(Wpv0);
+  off["Wpv0T"] = P.add(transposed(Wpv0, H + h2, H));
+  off["Wa0"] = P.add(*Wa0);
+  off["ba0"] = P.add(*ba0);
+  off["Wa0T"] = P.add(transposed(*Wa0, H, 2 * H));
+  off["Wb0"] = P.add(*Wb0);
+  off["bb0"] = P.add(*bb0);
+  off["Wb0T"] = P.add(transposed(*Wb0, H, H));
+  off["W11"] = P.add(*W11);
+  off["W11T"] = P.add(transposed(*W11, h2, h2));
+  off["Wa1"] = P.add(*Wa1);
+  off["ba1"] = P.add(*ba1);
+  off["Wa1T"] = P.add(transposed(*Wa1, h2, H));
+  {
+    std::vector<float> wb1(Wb1->begin(), Wb1->begin() + h2);
+    off["wb1"] = P.add(wb1);
+  }
+  bool has_ar = c->hp.has_atomref != 0;
+  if (has_ar) {
+    NEED(ar, "prior_model.atomref.weight", (size_t)Z);
+    off["atomref"] = P.add(*ar);
+  }
+#undef NEED
+
+  if (c->warena) {
+    hipFree(c->warena);
+    c->warena = nullptr;
+  }
+  HIPCHK(c, hipMalloc((void**)&c->warena, P.host.size() * sizeof(float)));
+  HIPCHK(c, hipMemcpy(c->warena, P.host.data(), P.host.size() * sizeof(float), hipMemcpyHostToDevice));
+  float* B = c->warena;
+  c->emb1 = B + off["emb1"];
+  c->emb2 = B + off["emb2"];
+  c->means = B + off["means"];
+  c->betas = B + off["betas"];
+  c->Wrbf = B + off["Wrbf"];
+  c->brbf = B + off["brbf"];
+  c->WrbfT = B + off["WrbfT"];
+  c->Wc = B + off["Wc"];
+  c->bc = B + off["bc"];
+  c->WcnT = B + off["WcnT"];
+  c->on_g = B + off["on_g"];
+  c->on_b = B + off["on_b"];
+  c->vo_w = B + off["vo_w"];
+  c->lw.resize(L);
+  for (int l = 0; l < L; ++l) {
+    auto& o = loff[l];
+    LayerW& w = c->lw[l];
+    w.Wqkv = B + o["Wqkv"];
+    w.bqkv = B + o["bqkv"];
+    w.WqkvT = B + o["WqkvT"];
+    w.Wv5 = B + o["Wv5"];
+    w.Wv5T = B + o["Wv5T"];
+    w.We3 = B + o["We3"];
+    w.be3 = B + o["be3"];
+    w.We3T = B + o["We3T"];
+    w.Ws = B + o["Ws"];
+    w.bs = B + o["bs"];
+    w.WsT = B + o["WsT"];
+    w.Wo = B + o["Wo"];
+    w.bo = B + o["bo"];
+    w.WoT = B + o["WoT"];
+    w.ln_g = B + o["ln_g"];
+    w.ln_b = B + o["ln_b"];
+    w.vln_w = B + o["vln_w"];
+  }
+  HeadW& hw = c->hw;
+  hw.Wpv0 = B + off["Wpv0"];
+  hw.Wpv0T = B + off["Wpv0T"];
+  hw.Wa0 = B + off["Wa0"];
+  hw.ba0 = B + off["ba0"];
+  hw.Wa0T = B + off["Wa0T"];
+  hw.Wb0 = B + off["Wb0"];
+  hw.bb0 = B + off["bb0"];
+  hw.Wb0T = B + off["Wb0T"];
+  hw.W11 = B + off["W11"];
+  hw.W11T = B + off["W11T"];
+  hw.Wa1 = B + off["Wa1"];
+  hw.ba1 = B + off["ba1"];
+  hw.Wa1T = B + off["Wa1T"];
+  hw.wb1 = B + off["wb1"];
+  hw.bb1 = (*bb1)[0];
+  hw.mean = (*meanv)[0];
+  hw.stdv = (*stdv)[0];
+  hw.atomref = has_ar ? B + off["atomref"] : nullptr;
+  c->finalized = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------
+static void carve(vsn_ctx* c, int N, int E, int Bn) {
+  Arena& a = c->ws;
+  a.off = 0;
+  const size_t H = c->H, S = c->S, Rp = c->Rp, h2 = c->H / 2, nh = c->nh;
+  const size_t n = N, e = E;
+  c->fstart = a.take<int>(Bn + 1);
+  c->fend = a.take<int>(Bn + 1);
+  c->deg = a.take<int>(n + 1);
+  c->zi = a.take<int>(n + 1);
+  c->rowptr = a.take<int>(n + 2);
+  c->colptr = a.take<int>(n + 2);
+  c->src = a.take<int>(e + 1);
+  c->tgt = a.take<int>(e + 1);
+  c->perm = a.take<int>(e + 1);
+  c->ecount = a.take<int>(64);
+  c->geo = a.take<float>(e * 8);
+  c->d = a.take<float>(e * 8);
+  c->rbf = a.take<float>(e * Rp);
+  c->drbf = a.take<float>(e * Rp);
+  c->pp = a.take<float>(e * 2 * H);
+  c->cat = a.take<float>(n * 2 * H);
+  c->x_emb = a.take<float>(n * H);
+  c->x = a.take<float>(n * H);
+  c->vec = a.take<float>(n * S * H);
+  c->f = a.take<float>(e * H);
+  c->lb.resize(c->L);
+  for (int l = 0; l < c->L; ++l) {
+    LayerBuf& b = c->lb[l];
+    b.xn = a.take<float>(n * H);
+    b.rstd = a.take<float>(n);
+    b.vh = a.take<float>(n * S * H);
+    b.qkv = a.take<float>(n * 3 * H);
+    b.vp = a.take<float>(n * S * 5 * H);
+    b.pe = a.take<float>(e * 3 * H);
+    b.tpre = a.take<float>(e * 2 * H);
+    b.o = a.take<float>(n * 3 * H);
+  }
+  c->xh = a.take<float>(n * H);
+  c->m = a.take<float>(e * H);
+  c->A = a.take<float>(n * H);
+  c->xn_o = a.take<float>(n * H);
+  c->rstd_o = a.take<float>(n);
+  c->vo = a.take<float>(n * S * H);
+  HeadBuf& hb = c->hb;
+  hb.cat0 = a.take<float>(n * 2 * H);
+  hb.pv0 = a.take<float>(n * S * (H + h2));
+  hb.a0 = a.take<float>(n * H);
+  hb.u0 = a.take<float>(n * H);
+  hb.vec1o = a.take<float>(n * S * h2);
+  hb.cat1 = a.take<float>(n * H);
+  hb.p1 = a.take<float>(n * S * h2);
+  hb.a1b = a.take<float>(n * h2);
+  hb.y = a.take<float>(n + 1);
+  hb.g_a1 = a.take<float>(n * h2);
+  hb.g_cat1 = a.take<float>(n * H);
+  hb.g_p1 = a.take<float>(n * S * h2);
+  hb.g_vec1o = a.take<float>(n * S * h2);
+  hb.g_u0 = a.take<float>(n * H);
+  hb.g_h0 = a.take<float>(n * H);
+  hb.g_cat0 = a.take<float>(n * 2 * H);
+  hb.g_pv0 = a.take<float>(n * S * (H + h2));
+  c->g_vo = a.take<float>(n * S * H);
+  c->g_x = a.take<float>(n * H);
+  c->g_vec = a.take<float>(n * S * H);
+  c->g_f = a.take<float>(e * H);
+  c->g_o = a.take<float>(n * 3 * H);
+  c->g_vp = a.take<float>(n * S * 5 * H);
+  c->g_A = a.take<float>(n * H);
+  c->g_t = a.take<float>(e * 2 * H);
+  c->g_m = a.take<float>(e * H);
+  c->g_pe = a.take<float>(e * 3 * H);
+  c->g_qkv = a.take<float>(n * 3 * H);
+  c->g_vh = a.take<float>(n * S * H);
+  c->g_xh = a.take<float>(n * H);
+  c->sat_tmp = a.take<float>(e * 2 * nh);
+  c->g_pp = a.take<float>(e * 2 * H);
+  c->g_n = a.take<float>(n * H);
+  c->g_rbf = a.take<float>(e * Rp);
+  c->g_geo = a.take<float>(e * 16);
+  c->g_ev = a.take<float>(e * 4);
+}
+
+static int ensure_ws(vsn_ctx* c, int N, int E, int Bn) {
+  if (N <= c->capN && E <= c->capE && Bn <= c->capB && c->ws.base) return 0;
+  int nN = std::max(N, c->capN), nE = std::max(E, c->capE), nB = std::max(Bn, c->capB);
+  // grow with head-room so MD loops with slightly varying edge bounds do not realloc
+  nN = std::max(nN, 64);
+  nE = std::max(nE, 1024);
+  nB = std::max(nB, 16);
+  c->ws.dry = true;
+  carve(c, nN, nE, nB);
+  size_t need = c->ws.off;
+  if (c->ws.base) {
+    HIPCHK(c, hipDeviceSynchronize());
+    hipFree(c->ws.base);
+    c->ws.base = nullptr;
+  }
+  hipError_t e = hipMalloc((void**)&c->ws.base, need);
+  if (e != hipSuccess) {
+    c->capN = c->capE = c->capB = 0;
+    return fail(c, -12, "workspace hipMalloc of " + std::to_string(need >> 20) + " MiB failed");
+  }
+  c->ws.cap = need;
+  c->ws.dry = false;
+  carve(c, nN, nE, nB);
+  c->capN = nN;
+  c->capE = nE;
+  c->capB = nB;
+  return 0;
+}
+
+static void snapshot(vsn_ctx* c, hipStream_t st, const char* name, int layer, const float* p, size_t elems) {
+  if (!c->debug) return;
+  auto& v = c->snap[name];
+  if ((int)v.size() < c->L + 1) v.resize(c->L + 1, nullptr);
+  size_t& cap = c->snap_elems[std::string(name) + "#" + std::to_string(layer)];
+  if (!v[layer] || cap < elems) {
+    if (v[layer]) hipFree(v[layer]);
+    hipMalloc((void**)&v[layer], std::max<size_t>(elems, 1) * sizeof(float));
+    cap = elems;
+  }
+  hipMemcpyAsync(v[layer], p, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
+// ---------------------------------------------------------------------------------
+// one chunk: forward + reverse
+// ---------------------------------------------------------------------------------
+static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* pos, const std::vector<int>& fs,
+                     const std::vector<int>& fe, int N, int Bn, int Emax, int maxfrag, float* e_out, float* f_out) {
+  int rc = ensure_ws(c, N, Emax, Bn);
+  if (rc) return rc;
+  const int H = c->H, L = c->L, S = c->S, Rp = c->Rp;
+  c->lastN = N;
+  c->lastB = Bn;
+  c->lastEmax = Emax;
+  // fragment offsets (small) - skip the upload when unchanged (MD: static fragmentation)
+  if (fs != c->h_fs || fe != c->h_fe) {
+    c->h_fs = fs;
+    c->h_fe = fe;
+    HIPCHK(c, hipMemcpyAsync(c->fstart, c->h_fs.data(), Bn * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->fend, c->h_fe.data(), Bn * sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  GraphArgs g;
+  g.pos = pos;
+  g.z64 = (const long long*)z;
+  g.fstart = c->fstart;
+  g.fend = c->fend;
+  g.B = Bn;
+  g.N = N;
+  g.Emax = Emax;
+  g.max_frag = maxfrag;
+  g.rc = c->hp.cutoff;
+  g.rc2 = c->hp.cutoff * c->hp.cutoff;
+  g.alpha = 5.0f / c->hp.cutoff;
+  g.max_nb = c->hp.max_num_neighbors;
+  g.R = c->R;
+  g.Rp = Rp;
+  g.S = S;
+  g.means = c->means;
+  g.betas = c->betas;
+  g.deg = c->deg;
+  g.zi = c->zi;
+  g.rowptr = c->rowptr;
+  g.colptr = c->colptr;
+  g.src = c->src;
+  g.tgt = c->tgt;
+  g.perm = c->perm;
+  g.ecount = c->ecount;
+  g.geo = c->geo;
+  g.d = c->d;
+  g.rbf = c->rbf;
+  g.drbf = c->drbf;
+  Dims D;
+  D.N = N;
+  D.Emax = Emax;
+  D.H = H;
+  D.S = S;
+  D.nh = c->nh;
+  D.R = c->R;
+  D.Rp = Rp;
+  D.ecount = c->ecount;
+  D.rowptr = c->rowptr;
+  D.colptr = c->colptr;
+  D.src = c->src;
+  D.tgt = c->tgt;
+  D.perm = c->perm;
+  D.zi = c->zi;
+  D.geo = c->geo;
+  D.d = c->d;
+  const int* EP = c->ecount;
+
+#define RC(call)            \
+  do {                      \
+    int r__ = (call);       \
+    if (r__) return fail(c, r__, std::string("launch failed: ") + #call); \
+  } while (0)
+
+  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, (size_t)Emax * 16 * sizeof(float), st));
+  HIPCHK(c, hipMemsetAsync(c->g_f, 0, (size_t)Emax * H * sizeof(float), st));
+  RC(launch_graph(st, g));
+  // ---- embeddings ----
+  RC(launch_gemm(st, c->rbf, Rp, c->Wrbf, Rp, c->pp, 2 * H, c->brbf, Emax, EP, 2 * H, Rp, 0));
+  RC(launch_embed_node(st, D, c->emb1, c->emb2, c->pp, c->cat));
+  RC(launch_gemm(st, c->cat, 2 * H, c->Wc, 2 * H, c->x_emb, H, c->bc, N, nullptr, H, 2 * H, 0));
+  HIPCHK(c, hipMemcpyAsync(c->x, c->x_emb, (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+  RC(launch_embed_edge(st, D, c->x_emb, c->pp, c->f, c->vec));
+  // ---- ViS-MP layers ----
+  for (int l = 0; l < L; ++l) {
+    const bool last = (l == L - 1);
+    const LayerW& w = c->lw[l];
+    LayerBuf& b = c->lb[l];
+    snapshot(c, st, "x_in", l, c->x, (size_t)N * H);
+    snapshot(c, st, "vec_in", l, c->vec, (size_t)N * S * H);
+    snapshot(c, st, "f_in", l, c->f, (size_t)Emax * H);
+    RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
+                        b.vh));
+    RC(launch_gemm(st, c->xh, H, w.Wqkv, H, b.qkv, 3 * H, w.bqkv, N, nullptr, 3 * H, H, 0));
+    RC(launch_gemm(st, b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0));
+    RC(launch_gemm(st, c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, last ? 2 * H : 3 * H, H, 0));
+    RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
+    snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
+    snapshot(c, st, "A", l, c->A, (size_t)N * H);
+    RC(launch_gemm(st, c->m, H, w.Ws, H, b.tpre, 2 * H, w.bs, Emax, EP, 2 * H, H, 0));
+    RC(launch_gemm(st, c->A, H, w.Wo, H, b.o, 3 * H, w.bo, N, nullptr, 3 * H, H, 0));
+    RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec));
+    if (!last) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
+  }
+  snapshot(c, st, "x_in", L, c->x, (size_t)N * H);
+  snapshot(c, st, "vec_in", L, c->vec, (size_t)N * S * H);
+  // ---- read-out ----
+  RC(launch_node_norm(st, D, c->x, c->vec, c->on_g, c->on_b, c->vo_w, c->hp.vecnorm_type, c->xn_o, c->rstd_o,
+                      c->hb.cat0, 2 * H, c->vo));
+  RC(launch_head_forward(st, D, c->hw, c->hb, c->vo, c->fstart, c->fend, Bn, e_out));
+  // ---- reverse pass ----
+  RC(launch_head_backward(st, D, c->hw, c->hb, c->g_vo));
+  RC(launch_bwd_node_norm(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w,
+                          c->hp.vecnorm_type, 0, c->g_x, c->g_vec));
+  snapshot(c, st, "g_x_in", L, c->g_x, (size_t)N * H);
+  snapshot(c, st, "g_vec_in", L, c->g_vec, (size_t)N * S * H);
+  for (int l = L - 1; l >= 0; --l) {
+    const bool last = (l == L - 1);
+    const LayerW& w = c->lw[l];
+    LayerBuf& b = c->lb[l];
+    RC(launch_bwd_node_update(st, D, c->g_x, c->g_vec, b.vp, b.o, c->g_o, c->g_vp));
+    RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));
+    if (!last) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
+    RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, c->g_vh, c->g_geo));
+    snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
+    RC(launch_gemm(st, c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0));
+    RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo));
+    snapshot(c, st, "g_m", l, c->g_m, (size_t)Emax * H);
+    snapshot(c, st, "g_pe", l, c->g_pe, (size_t)Emax * 3 * H);
+    snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);
+    snapshot(c, st, "g_vp", l, c->g_vp, (size_t)N * S * 5 * H);
+    snapshot(c, st, "g_A", l, c->g_A, (size_t)N * H);
+    RC(launch_gemm(st, c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H, last ? 2 * H : 3 * H, 1));
+    RC(launch_gemm(st, c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
+                   last ? 3 * H : 5 * H, 1));
+    RC(launch_gemm(st, c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0));
+    snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
+    snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
+    RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, c->hp.vecnorm_type, 1,
+                            c->g_x, c->g_vec));
+    snapshot(c, st, "g_x_in", l, c->g_x, (size_t)N * H);
+    snapshot(c, st, "g_vec_in", l, c->g_vec, (size_t)N * S * H);
+    snapshot(c, st, "g_f_in", l, c->g_f, (size_t)Emax * H);
+  }
+  // ---- embeddings, reverse ----
+  RC(launch_bwd_embed_edge(st, D, c->x_emb, c->pp, c->g_f, c->g_pp, c->g_x));
+  RC(launch_gemm(st, c->g_x, H, c->WcnT, H, c->g_n, H, nullptr, N, nullptr, H, H, 0));
+  RC(launch_bwd_embed_node(st, D, c->emb2, c->pp, c->g_n, c->g_pp, c->g_geo));
+  RC(launch_gemm(st, c->g_pp, 2 * H, c->WrbfT, 2 * H, c->g_rbf, Rp, nullptr, Emax, EP, Rp, 2 * H, 0));
+  RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out));
+#undef RC
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(c, -5, std::string("kernel launch error: ") + hipGetErrorString(le));
+  return 0;
+}
+
+extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_pos, const int64_t* host_start,
+                          const int64_t* host_end, int64_t N, int64_t B, float* dev_e_out, float* dev_f_out,
+                          void* stream) {
+  if (!c) return -22;
+  if (!c->finalized) return fail(c, -22, "vsn_finalize() has not been called");
+  if (N < 0 || B < 0) return fail(c, -22, "negative sizes");
+  if (B == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  // validate layout: contiguous ascending fragments covering [0,N)
+  int64_t prev = 0;
+  for (int64_t b = 0; b < B; ++b) {
+    if (host_start[b] != prev || host_end[b] < host_start[b])
+      return fail(c, -22, "fragments must be contiguous and ascending (start[b] == end[b-1])");
+    if (host_end[b] - host_start[b] > VSN_MAX_FRAG_ATOMS)
+      return fail(c, -22, "fragment larger than VSN_MAX_FRAG_ATOMS");
+    prev = host_end[b];
+  }
+  if (prev != N) return fail(c, -22, "fragment offsets do not cover N atoms");
+  const int64_t mnb = c->hp.max_num_neighbors;
+  int64_t b0 = 0;
+  while (b0 < B) {
+    // greedy chunk by the host-side edge bound sum n*min(n,max_nb)
+    int64_t eb = 0, b1 = b0, maxfrag = 0;
+    while (b1 < B) {
+      int64_t n = host_end[b1] - host_start[b1];
+      int64_t add = n * std::min<int64_t>(n, mnb);
+      if (b1 > b0 && eb + add > c->max_chunk_edges) break;
+      eb += add;
+      maxfrag = std::max(maxfrag, n);
+      ++b1;
+    }
+    const int64_t a0 = host_start[b0], a1 = host_end[b1 - 1];
+    std::vector<int> fs((size_t)(b1 - b0)), fe((size_t)(b1 - b0));
+    for (int64_t b = b0; b < b1; ++b) {
+      fs[(size_t)(b - b0)] = (int)(host_start[b] - a0);
+      fe[(size_t)(b - b0)] = (int)(host_end[b] - a0);
+    }
+    int rc = run_chunk(c, st, dev_z + a0, dev_pos + 3 * a0, fs, fe, (int)(a1 - a0), (int)(b1 - b0), (int)eb,
+                       (int)maxfrag, dev_e_out + b0, dev_f_out + 3 * a0);
+    if (rc) return rc;
+    b0 = b1;
+  }
+  return 0;
+}
+
+extern "C" int64_t vsn_last_num_edges(vsn_handle c) {
+  if (!c || !c->ws.base) return -22;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  int e = 0;
+  if (hipMemcpy(&e, c->ecount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -5;
+  return e;
+}
+
+extern "C" int64_t vsn_debug_read(vsn_handle c, const char* name, int layer, void* host_out, int64_t max_elems) {
+  if (!c || !name || !c->ws.base) return -22;
+  hipSetDevice(c->device);
+  if (hipDeviceSynchronize() != hipSuccess) return fail(c, -5, "device sync failed");
+  int E = 0;
+  hipMemcpy(&E, c->ecount, sizeof(int), hipMemcpyDeviceToHost);
+  const size_t N = c->lastN, H = c->H, S = c->S, Rp = c->Rp, h2 = c->H / 2, e = E, Bn = c->lastB;
+  const std::string k(name);
+  const void* p = nullptr;
+  size_t n = 0;
+  auto L_ok = layer >= 0 && layer < c->L;
+#define TAP(nm, ptr, cnt) \
+  if (k == nm) {          \
+    p = (ptr);            \
+    n = (cnt);            \
+  }
+  TAP("rowptr", c->rowptr, N + 1)
+  TAP("colptr", c->colptr, N + 1)
+  TAP("src", c->src, e)
+  TAP("tgt", c->tgt, e)
+  TAP("perm", c->perm, e)
+  TAP("geo", c->geo, e * 8)
+  TAP("d", c->d, e * 8)
+  TAP("rbf", c->rbf, e * Rp)
+  TAP("drbf", c->drbf, e * Rp)
+  TAP("pp", c->pp, e * 2 * H)
+  TAP("cat", c->cat, N * 2 * H)
+  TAP("x_emb", c->x_emb, N * H)
+  TAP("x", c->x, N * H)
+  TAP("vec", c->vec, N * S * H)
+  TAP("f", c->f, e * H)
+  TAP("cat0", c->hb.cat0, N * 2 * H)
+  TAP("vo", c->vo, N * S * H)
+  TAP("pv0", c->hb.pv0, N * S * (H + h2))
+  TAP("a0", c->hb.a0, N * H)
+  TAP("u0", c->hb.u0, N * H)
+  TAP("p1", c->hb.p1, N * S * h2)
+  TAP("cat1", c->hb.cat1, N * H)
+  TAP("a1b", c->hb.a1b, N * h2)
+  TAP("y", c->hb.y, N)
+  TAP("g_cat0", c->hb.g_cat0, N * 2 * H)
+  TAP("g_vo", c->g_vo, N * S * H)
+  TAP("g_x", c->g_x, N * H)
+  TAP("g_n", c->g_n, N * H)
+  TAP("g_pp", c->g_pp, e * 2 * H)
+  TAP("g_rbf", c->g_rbf, e * Rp)
+  TAP("g_geo", c->g_geo, e * 16)
+  TAP("g_ev", c->g_ev, e * 4)
+  if (L_ok) {
+    const LayerBuf& b = c->lb[layer];
+    TAP("xn", b.xn, N * H)
+    TAP("rstd", b.rstd, N)
+    TAP("vh", b.vh, N * S * H)
+    TAP("qkv", b.qkv, N * 3 * H)
+    TAP("vp", b.vp, N * S * 5 * H)
+    TAP("pe", b.pe, e * 3 * H)
+    TAP("tpre", b.tpre, e * 2 * H)
+    TAP("o", b.o, N * 3 * H)
+  }
+#undef TAP
+  if (!p) {
+    auto it = c->snap.find(k);
+    if (it != c->snap.end() && layer >= 0 && layer < (int)it->second.size() && it->second[layer]) {
+      p = it->second[layer];
+      size_t cap = c->snap_elems[k + "#" + std::to_string(layer)];
+      // edge-sized snapshots were taken with Emax rows; report the live rows only
+      n = cap;
+      if (k == "f_in" || k == "m" || k == "g_m" || k == "g_f_in") n = e * H;
+      if (k == "g_t") n = e * 2 * H;
+      if (k == "g_pe") n = e * 3 * H;
+    }
+  }
+  (void)Bn;
+  if (!p) return fail(c, -2, "unknown debug tap " + k);
+  if ((int64_t)n > max_elems) n = (size_t)max_elems;
+  if (hipMemcpy(host_out, p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(c, -5, "debug copy failed");
+  return (int64_t)n;
+}
+
+extern "C" int vsn_gemm(vsn_handle c, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
+                        const float* bias, int M, int Nc, int K, int flags, void* stream) {
+  if (!c) return -22;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = launch_gemm((hipStream_t)stream, A, lda, Bt, ldb, C, ldc, bias, M, nullptr, Nc, K, flags);
+  if (rc) return fail(c, rc, "gemm: unsupported shape (K, Nc multiples of 32; lda/ldb multiples of 4)");
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) return fail(c, -5, hipGetErrorString(le));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// combine plan (Calculators/combiner.py:24-41)
+// ---------------------------------------------------------------------------------
+struct vsn_combine_plan {
+  int device = 0;
+  int n_prot = 0;
+  int* off = nullptr;
+  int* rows = nullptr;
+  float* sign = nullptr;
+};
+
+extern "C" int vsn_combine_plan_create(vsn_combine_handle* out, int device_id, int64_t n_prot, int64_t n_cat,
+                                       int64_t n_dip_rows, const int64_t* row_of_cat, const int64_t* select,
+                                       const int64_t* origin, int64_t n_select) {
+  if (!out || n_prot < 0 || n_select < 0) return -22;
+  for (int64_t k = 0; k < n_select; ++k) {
+    if (select[k] < 0 || select[k] >= n_cat || origin[k] < 0 || origin[k] >= n_prot) return -22;
+  }
+  std::vector<int> off((size_t)n_prot + 1, 0), rows((size_t)n_select);
+  std::vector<float> sign((size_t)n_select);
+  for (int64_t k = 0; k < n_select; ++k) off[(size_t)origin[k] + 1]++;
+  for (int64_t a = 0; a < n_prot; ++a) off[(size_t)a + 1] += off[(size_t)a];
+  std::vector<int> cur(off.begin(), off.end() - 1);
+  for (int64_t k = 0; k < n_select; ++k) {  // stable: ascending k inside each origin
+    int slot = cur[(size_t)origin[k]]++;
+    rows[(size_t)slot] = (int)row_of_cat[select[k]];
+    sign[(size_t)slot] = select[k] < n_dip_rows ? 1.0f : -1.0f;
+  }
+  if (hipSetDevice(device_id) != hipSuccess) return -19;
+  vsn_combine_plan* p = new vsn_combine_plan();
+  p->device = device_id;
+  p->n_prot = (int)n_prot;
+  if (hipMalloc((void**)&p->off, off.size() * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&p->rows, std::max<size_t>(rows.size(), 1) * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&p->sign, std::max<size_t>(sign.size(), 1) * sizeof(float)) != hipSuccess) {
+    delete p;
+    return -12;
+  }
+  hipMemcpy(p->off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice);
+  if (n_select) {
+    hipMemcpy(p->rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice);
+    hipMemcpy(p->sign, sign.data(), sign.size() * sizeof(float), hipMemcpyHostToDevice);
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" void vsn_combine_plan_destroy(vsn_combine_handle p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  hipFree(p->off);
+  hipFree(p->rows);
+  hipFree(p->sign);
+  delete p;
+}
+
+extern "C" int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float* dev_f_prot, void* stream) {
+  if (!p) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  launch_combine((hipStream_t)stream, p->n_prot, p->off, p->rows, p->sign, dev_f_frag, dev_f_prot);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------
+// work partitions (Calculators/device_strategy.py:84-127): contiguous, atom-balanced
+// blocks per device, each cut into chunks of at most ~chunk_atoms atoms, a
+// straddling fragment going to the nearer side.
+// ---------------------------------------------------------------------------------
+static int64_t bisect_right(const int64_t* a, int64_t n, int64_t x) {
+  return std::upper_bound(a, a + n, x) - a;
+}
+
+extern "C" int vsn_partition(const int64_t* start, const int64_t* end, int64_t B, int n_devices, int64_t chunk,
+                             int64_t* out, int max_out) {
+  if (!start || !end || B <= 0 || n_devices <= 0 || chunk <= 0) return -22;
+  int cnt = 0;
+  int64_t b_prev = 0;
+  const int64_t a_end = B;
+  for (int i = 0; i < n_devices; ++i) {
+    if (b_prev >= a_end) break;  // (reference would raise IndexError here)
+    int64_t block = (end[B - 1] - start[b_prev]) / (n_devices - i);
+    int64_t b_end = bisect_right(start, B, block + start[b_prev]);
+    int64_t b_idx = b_end - 1;
+    int64_t block_end = block + start[b_prev];
+    if ((block_end - start[b_idx]) < (end[b_idx] - block_end)) b_end -= 1;
+    b_end = std::min(b_end, a_end);
+    if (i == n_devices - 1) b_end = a_end;
+    int64_t c_prev = b_prev;
+    while (c_prev != b_end) {
+      int64_t c_end = bisect_right(start, B, chunk + start[c_prev]);
+      int64_t c_idx = c_end - 1;
+      int64_t chunk_end = chunk + start[c_prev];
+      if ((chunk_end - start[c_idx]) < (end[c_idx] - chunk_end)) c_end -= 1;
+      c_end = std::min(c_end, b_end);
+      if (c_end <= c_prev) c_end = c_prev + 1;  // a fragment larger than the chunk (reference would spin)
+      if (cnt < max_out) {
+        out[3 * cnt + 0] = i;
+        out[3 * cnt + 1] = c_prev;
+        out[3 * cnt + 2] = c_end;
+      }
+      ++cnt;
+      c_prev = c_end;
+    }
+    b_prev = b_end;
+  }
+  return cnt;
+}

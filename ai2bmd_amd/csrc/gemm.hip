@@ -1,0 +1,171 @@
+// fp32 MFMA GEMM for the dense linear blocks of ViSNet (reference: every
+// nn.Linear in ViSNet/model/visnet_block.py:183-203, utils.py:282-283,323,
+// output_modules.py:30-39 and their input-gradient products).
+//
+//   C[M,Nc] (+)= f(A)[M,K] * Bt[Nc,K]^T (+ bias[Nc])
+//
+// A is row-major with K contiguous (activations), Bt is the nn.Linear weight
+// layout [out,in] (K contiguous) so forward products need no transpose; the
+// reverse pass uses pre-transposed weight copies made once at load time.
+// Arithmetic: v_mfma_f32_32x32x2_f32 - exact fp32 (an fmaf chain), 157 TF peak.
+//
+// Tile: BM x BN per 256-thread workgroup (4 waves as WM x WN), BK = 32.
+// LDS rows are padded to 36 floats so the ds_read_b128 fragment reads of a
+// 16-lane service group land in 16 distinct 16-byte slots (conflict free).
+// Each lane reads 4 consecutive k of its row: lanes 0-31 take k0..k0+3, lanes
+// 32-63 take k0+4..k0+7; MFMA #t pairs (k0+t, k0+4+t) for A and B alike, so
+// the k-sum is just reordered.
+#include "common.h"
+#include "kernels.h"
+
+namespace vsn {
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
+                                              const float* __restrict__ Bt, int ldb,
+                                              float* __restrict__ C, int ldc,
+                                              const float* __restrict__ bias, int M,
+                                              const int* __restrict__ Mptr, int Nc, int K, int flags) {
+  constexpr int BK = 32;
+  constexpr int LS = BK + 4;  // padded LDS row stride (floats)
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int MI = TM / 32, NI = TN / 32;
+  constexpr int LA = BM / 32, LB = BN / 32;  // float4 loads per thread per k-tile
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
+  float* As = smem;
+  float* Bs = smem + BM * LS;
+
+  int Meff = M;
+  if (Mptr) {
+    int md = *Mptr;
+    Meff = md < M ? md : M;
+  }
+  const int tiles_n = Nc / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+  if (row0 >= Meff) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const bool silu_a = (flags & 2) != 0;
+
+  f32x4 ra[LA], rb[LB];
+#define VSN_GLOAD(k0)                                                                        \
+  {                                                                                          \
+    _Pragma("unroll") for (int it = 0; it < LA; ++it) {                                      \
+      const int f_ = tid + it * 256;                                                         \
+      const int r_ = f_ >> 3, c4_ = f_ & 7;                                                  \
+      int gr_ = row0 + r_;                                                                   \
+      gr_ = gr_ < Meff ? gr_ : Meff - 1; /* clamp: rows >= Meff are never stored */          \
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4);     \
+    }                                                                                        \
+    _Pragma("unroll") for (int it = 0; it < LB; ++it) {                                      \
+      const int f_ = tid + it * 256;                                                         \
+      const int r_ = f_ >> 3, c4_ = f_ & 7;                                                  \
+      rb[it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r_) * ldb + (k0) + c4_ * 4); \
+    }                                                                                        \
+  }
+#define VSN_SSTORE()                                                          \
+  {                                                                           \
+    _Pragma("unroll") for (int it = 0; it < LA; ++it) {                       \
+      const int f_ = tid + it * 256;                                          \
+      const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
+      f32x4 v_ = ra[it];                                                     \
+      if (silu_a) {                                                           \
+        v_.x = silu_f(v_.x);                                                  \
+        v_.y = silu_f(v_.y);                                                  \
+        v_.z = silu_f(v_.z);                                                  \
+        v_.w = silu_f(v_.w);                                                  \
+      }                                                                       \
+      *reinterpret_cast<f32x4*>(As + r_ * LS + c4_ * 4) = v_;                \
+    }                                                                         \
+    _Pragma("unroll") for (int it = 0; it < LB; ++it) {                       \
+      const int f_ = tid + it * 256;                                          \
+      const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
+      *reinterpret_cast<f32x4*>(Bs + r_ * LS + c4_ * 4) = rb[it];            \
+    }                                                                         \
+  }
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = K / BK;
+  VSN_GLOAD(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    VSN_SSTORE();
+    __syncthreads();
+    {
+      // always prefetch (the last iteration re-reads its own tile; harmless, keeps ra/rb in registers)
+      const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK;
+      VSN_GLOAD(kn);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        a[i] = *reinterpret_cast<const f32x4*>(As + (wm * TM + i * 32 + l31) * LS + kk * 8 + hi * 4);
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * TN + j * 32 + l31) * LS + kk * 8 + hi * 4);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  const bool accum = (flags & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = col0 + wn * TN + j * 32 + l31;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < Meff) {
+          float* cp = C + (size_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (accum) v += *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
+int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
+                const float* bias, int M, const int* Mptr, int Nc, int K, int flags) {
+  if (M <= 0) return 0;
+  if ((K & 31) || (Nc & 31) || (lda & 3) || (ldb & 3)) return -22;
+  if ((Nc % 128) == 0 && M >= 2048) {
+    int grid = ((M + 127) / 128) * (Nc / 128);
+    hipLaunchKernelGGL((k_gemm<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+                       Mptr, Nc, K, flags);
+  } else if ((Nc % 64) == 0) {
+    int grid = ((M + 63) / 64) * (Nc / 64);
+    hipLaunchKernelGGL((k_gemm<64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+                       Mptr, Nc, K, flags);
+  } else {
+    int grid = ((M + 127) / 128) * (Nc / 32);
+    hipLaunchKernelGGL((k_gemm<128, 32, 4, 1>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+                       Mptr, Nc, K, flags);
+  }
+  return 0;
+}
+
+}  // namespace vsn

@@ -1,0 +1,299 @@
+// Neighbour list + pair geometry for a batch of fragments.
+//
+// Reference: ViSNet/model/utils.py:259-276 (Distance.forward ->
+// torch_cluster.radius_graph(loop=True, max_num_neighbors)), visnet_block.py:111-117
+// (unit vectors, Sphere), utils.py:16-19,53-57 (CosineCutoff, ExpNormalSmearing),
+// utils.py:131-160 (real spherical harmonics).
+//
+// Output: edges (j -> i) in CSR order by target i, sources ascending (the order
+// torch_cluster's CUDA kernel produces), at most max_nb sources per target
+// keeping the lowest indices, self loops kept; plus the same edge set grouped
+// by source (perm/colptr) for the reverse pass' deterministic segmented sums.
+// One workgroup per fragment; fragments are tiny (<= 44 atoms in AI2BMD) but
+// any size up to VSN_MAX_FRAG_ATOMS works (whole-molecule mode, B = 1).
+#include "common.h"
+#include "kernels.h"
+
+namespace vsn {
+
+__device__ __forceinline__ float dist2(const float* __restrict__ pos, int a, int b) {
+  float dx = pos[3 * a + 0] - pos[3 * b + 0];
+  float dy = pos[3 * a + 1] - pos[3 * b + 1];
+  float dz = pos[3 * a + 2] - pos[3 * b + 2];
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// pass 1: truncated in-degree per target; also narrows z to int32
+__global__ void k_graph_count(const float* __restrict__ pos, const long long* __restrict__ z64,
+                              const int* __restrict__ fstart, const int* __restrict__ fend, int* __restrict__ deg,
+                              int* __restrict__ zi, float rc2, int max_nb) {
+  const int b = blockIdx.x;
+  const int s = fstart[b], n = fend[b] - s;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int cnt = 0;
+    for (int j = 0; j < n && cnt < max_nb; ++j)
+      if (dist2(pos, s + j, s + i) < rc2) ++cnt;
+    deg[s + i] = cnt;
+    zi[s + i] = (int)z64[s + i];
+  }
+}
+
+// exclusive scan of deg[0..N) -> rowptr[0..N], total -> *ecount ; one block
+__global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, int* __restrict__ rowptr,
+                                               int* __restrict__ colptr, int N, int* __restrict__ ecount) {
+  __shared__ int part[1024];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    int i = base + tid;
+    int v = i < N ? deg[i] : 0;
+    part[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = tid >= o ? part[tid - o] : 0;
+      __syncthreads();
+      part[tid] += t;
+      __syncthreads();
+    }
+    int incl = part[tid];
+    int carry = carry_s;
+    if (i < N) rowptr[i] = carry + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    rowptr[N] = carry_s;
+    colptr[N] = carry_s;
+    *ecount = carry_s;
+  }
+}
+
+// pass 2: fill src/tgt in CSR-by-target order, then the by-source view.
+__global__ void k_graph_fill(const float* __restrict__ pos, const int* __restrict__ fstart,
+                             const int* __restrict__ fend, const int* __restrict__ rowptr, int* __restrict__ src,
+                             int* __restrict__ tgt, int* __restrict__ colptr, int* __restrict__ perm, float rc2,
+                             int max_nb) {
+  extern __shared__ int sm[];  // outdeg / prefix per local node (n ints) + 1
+  const int b = blockIdx.x;
+  const int s = fstart[b], n = fend[b] - s;
+  if (n <= 0) {
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int e = rowptr[s + i];
+    int cnt = 0;
+    for (int j = 0; j < n && cnt < max_nb; ++j)
+      if (dist2(pos, s + j, s + i) < rc2) {
+        src[e] = s + j;
+        tgt[e] = s + i;
+        ++e;
+        ++cnt;
+      }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // out-degree of every source j: targets i that kept j
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!(dist2(pos, s + j, s + i) < rc2)) continue;
+      int lo = rowptr[s + i], hi = rowptr[s + i + 1];
+      // row is ascending in source: binary search for s+j
+      int key = s + j;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int v = src[mid];
+        if (v < key)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo < rowptr[s + i + 1] && src[lo] == key) ++cnt;
+    }
+    sm[j] = cnt;
+  }
+  __syncthreads();
+  // exclusive scan of sm[0..n) (fragments are small: serial by one thread is fine
+  // up to a few thousand atoms; chunked for larger)
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int j = 0; j < n; ++j) {
+      int v = sm[j];
+      sm[j] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  const int ebase = rowptr[s];
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    int out = ebase + sm[j];
+    colptr[s + j] = out;
+    for (int i = 0; i < n; ++i) {
+      if (!(dist2(pos, s + j, s + i) < rc2)) continue;
+      int lo = rowptr[s + i], hi = rowptr[s + i + 1];
+      int key = s + j;
+      while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        int v = src[mid];
+        if (v < key)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      if (lo < rowptr[s + i + 1] && src[lo] == key) perm[out++] = lo;
+    }
+  }
+}
+
+// per-edge geometry: one thread per (edge, rbf index); Rp = padded rbf count (multiple of 32)
+__global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ tgt,
+                            const int* __restrict__ ecount, const float* __restrict__ means,
+                            const float* __restrict__ betas, int R, int Rp, float rc, float alpha, int S,
+                            float* __restrict__ geo /*[E,8]: r,C,dC,ux,uy,uz,rinv,pad*/, float* __restrict__ d,
+                            float* __restrict__ rbf, float* __restrict__ drbf) {
+  const int E = *ecount;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long e = gid / Rp;
+  const int k = (int)(gid % Rp);
+  if (e >= E) return;
+  const int j = src[e], i = tgt[e];
+  float ex = pos[3 * j + 0] - pos[3 * i + 0];
+  float ey = pos[3 * j + 1] - pos[3 * i + 1];
+  float ez = pos[3 * j + 2] - pos[3 * i + 2];
+  const bool loop = (i == j);
+  float r = loop ? 0.f : sqrtf(ex * ex + ey * ey + ez * ez);
+  float rinv = loop ? 0.f : 1.0f / r;
+  const float pi_rc = 3.14159265358979323846f / rc;
+  float inside = (r < rc) ? 1.f : 0.f;
+  float C = 0.5f * (cosf(r * pi_rc) + 1.0f) * inside;
+  float dC = -0.5f * pi_rc * sinf(r * pi_rc) * inside;
+  if (k < R) {
+    float t = expf(-alpha * r);
+    float mu = means[k], be = betas[k];
+    float ek = expf(-be * (t - mu) * (t - mu));
+    float dek = 2.0f * alpha * be * t * (t - mu) * ek;
+    rbf[e * Rp + k] = C * ek;
+    drbf[e * Rp + k] = dC * ek + C * dek;
+  } else {
+    rbf[e * Rp + k] = 0.f;
+    drbf[e * Rp + k] = 0.f;
+  }
+  if (k == 0) {
+    float ux = ex * rinv, uy = ey * rinv, uz = ez * rinv;
+    float* g = geo + e * 8;
+    g[0] = r;
+    g[1] = C;
+    g[2] = dC;
+    g[3] = ux;
+    g[4] = uy;
+    g[5] = uz;
+    g[6] = rinv;
+    g[7] = 0.f;
+    float* dd = d + e * 8;
+    const float s3 = 1.7320508075688772f;
+    dd[0] = ux;
+    dd[1] = uy;
+    dd[2] = uz;
+    if (S == 8) {
+      dd[3] = s3 * ux * uz;
+      dd[4] = s3 * ux * uy;
+      dd[5] = uy * uy - 0.5f * (ux * ux + uz * uz);
+      dd[6] = s3 * uy * uz;
+      dd[7] = 0.5f * s3 * (uz * uz - ux * ux);
+    } else {
+      dd[3] = dd[4] = dd[5] = dd[6] = dd[7] = 0.f;
+    }
+  }
+}
+
+// reverse of the geometry: dE/d(edge vector) per edge from the accumulated
+// dE/dr-ish terms (g_rbf . drbf + g_C * dC) and dE/dd (through the SH Jacobian
+// and the unit-vector normalisation).  one thread per edge.
+__global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restrict__ geo,
+                           const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
+                           const float* __restrict__ g_geo /*[E,16]: g_d[8] at 0..7, g_C at 8*/, int S,
+                           float* __restrict__ g_ev /*[E,4]*/) {
+  const int E = *ecount;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const float* g = geo + (size_t)e * 8;
+  const float dC = g[2], ux = g[3], uy = g[4], uz = g[5], rinv = g[6];
+  float gr = g_geo[(size_t)e * 16 + 8] * dC;
+  const float* gb = g_rbf + (size_t)e * Rp;
+  const float* db = drbf + (size_t)e * Rp;
+  for (int k = 0; k < Rp; ++k) gr += gb[k] * db[k];
+  const float* gd = g_geo + (size_t)e * 16;
+  const float s3 = 1.7320508075688772f;
+  float gx = gd[0], gy = gd[1], gz = gd[2];
+  if (S == 8) {
+    gx += s3 * uz * gd[3] + s3 * uy * gd[4] - ux * gd[5] - s3 * ux * gd[7];
+    gy += s3 * ux * gd[4] + 2.0f * uy * gd[5] + s3 * uz * gd[6];
+    gz += s3 * ux * gd[3] - uz * gd[5] + s3 * uy * gd[6] + s3 * uz * gd[7];
+  }
+  float dot = gx * ux + gy * uy + gz * uz;
+  float ox = gr * ux + (gx - dot * ux) * rinv;
+  float oy = gr * uy + (gy - dot * uy) * rinv;
+  float oz = gr * uz + (gz - dot * uz) * rinv;
+  if (rinv == 0.f) ox = oy = oz = 0.f;  // self loop: no position dependence
+  float* o = g_ev + (size_t)e * 4;
+  o[0] = ox;
+  o[1] = oy;
+  o[2] = oz;
+  o[3] = 0.f;
+}
+
+// F_i = -dE/dpos_i = sum_{e: tgt=i} g_ev_e - sum_{e: src=i} g_ev_e  (ev = pos_src - pos_tgt), fixed order
+__global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                               const int* __restrict__ perm, const float* __restrict__ g_ev,
+                               float* __restrict__ f_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) {
+    fx += g_ev[4 * (size_t)e + 0];
+    fy += g_ev[4 * (size_t)e + 1];
+    fz += g_ev[4 * (size_t)e + 2];
+  }
+  for (int t = colptr[i]; t < colptr[i + 1]; ++t) {
+    int e = perm[t];
+    fx -= g_ev[4 * (size_t)e + 0];
+    fy -= g_ev[4 * (size_t)e + 1];
+    fz -= g_ev[4 * (size_t)e + 2];
+  }
+  f_out[3 * (size_t)i + 0] = fx;
+  f_out[3 * (size_t)i + 1] = fy;
+  f_out[3 * (size_t)i + 2] = fz;
+}
+
+int launch_graph(hipStream_t st, const GraphArgs& a) {
+  if (a.B <= 0 || a.N <= 0) return 0;
+  hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
+                     a.max_nb);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
+  size_t shm = (size_t)(a.max_frag + 1) * sizeof(int);
+  hipLaunchKernelGGL(k_graph_fill, dim3(a.B), dim3(64), shm, st, a.pos, a.fstart, a.fend, a.rowptr, a.src, a.tgt,
+                     a.colptr, a.perm, a.rc2, a.max_nb);
+  long long tot = (long long)a.Emax * a.Rp;
+  int blocks = (int)((tot + 255) / 256);
+  if (blocks > 0)
+    hipLaunchKernelGGL(k_edge_geom, dim3(blocks), dim3(256), 0, st, a.pos, a.src, a.tgt, a.ecount, a.means, a.betas,
+                       a.R, a.Rp, a.rc, a.alpha, a.S, a.geo, a.d, a.rbf, a.drbf);
+  return 0;
+}
+
+int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
+                    float* f_out) {
+  if (a.N <= 0) return 0;
+  int blocks = (a.Emax + 255) / 256;
+  if (blocks > 0)
+    hipLaunchKernelGGL(k_bwd_geom, dim3(blocks), dim3(256), 0, st, a.ecount, a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S,
+                       g_ev);
+  hipLaunchKernelGGL(k_force_gather, dim3((a.N + 255) / 256), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
+                     g_ev, f_out);
+  return 0;
+}
+
+}  // namespace vsn

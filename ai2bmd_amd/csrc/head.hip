@@ -1,0 +1,187 @@
+// Read-out head: two GatedEquivariantBlocks + per-fragment energy sum, and its
+// reverse pass.  Reference: ViSNet/model/output_modules.py:52-62 (block forward),
+// :136-140 (EquivariantScalar.pre_reduce), ViSNet/model/visnet.py:139-149
+// (x*std, Atomref prior priors.py:86-87, scatter-sum per molecule, +mean).
+//
+// Block 1's vec2_proj / gate only feed `v.sum() * 0` (output_modules.py:140) and
+// are therefore not evaluated.  The dense products run on the MFMA GEMM; the
+// elementwise glue here is N-sized (negligible next to the E-sized layer work).
+#include "common.h"
+#include "kernels.h"
+
+namespace vsn {
+
+// out[i*ldo + off + c] = || p[(i*S+s)*ldp + c] ||_2 over s
+__global__ void hk_norm_s(int N, int S, int C, const float* __restrict__ p, int ldp, float* __restrict__ out,
+                          int ldo, int off) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)N * C) return;
+  const int i = (int)(gid / C), c = (int)(gid % C);
+  float s2 = 0.f;
+  for (int s = 0; s < S; ++s) {
+    float v = p[((size_t)i * S + s) * ldp + c];
+    s2 += v * v;
+  }
+  out[(size_t)i * ldo + off + c] = sqrtf(s2);
+}
+
+// x1 = silu(xs) -> cat1[:, :h2] ; vec1o[s] = gate * v2[s]
+__global__ void hk_mid(int N, int S, int H, const float* __restrict__ u0, const float* __restrict__ pv0, int ldp,
+                       float* __restrict__ cat1, float* __restrict__ vec1o) {
+  const int h2 = H / 2;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)N * h2) return;
+  const int i = (int)(gid / h2), c = (int)(gid % h2);
+  cat1[(size_t)i * H + c] = silu_f(u0[(size_t)i * H + c]);
+  const float gate = u0[(size_t)i * H + h2 + c];
+  for (int s = 0; s < S; ++s)
+    vec1o[((size_t)i * S + s) * h2 + c] = gate * pv0[((size_t)i * S + s) * ldp + H + c];
+}
+
+// y_i = std * (wb1 . silu(a1b_i) + bb1) + atomref[z_i]
+__global__ void hk_final(int N, int h2, const float* __restrict__ a1b, const float* __restrict__ wb1, float bb1,
+                         float stdv, const float* __restrict__ atomref, const int* __restrict__ zi,
+                         float* __restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float acc = 0.f;
+  for (int c = 0; c < h2; ++c) acc += silu_f(a1b[(size_t)i * h2 + c]) * wb1[c];
+  float v = (acc + bb1) * stdv;
+  if (atomref) v += atomref[zi[i]];
+  y[i] = v;
+}
+
+__global__ void hk_energy(int B, const int* __restrict__ fstart, const int* __restrict__ fend,
+                          const float* __restrict__ y, float mean, float* __restrict__ e_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int i = fstart[b]; i < fend[b]; ++i) acc += y[i];
+  e_out[b] = acc + mean;
+}
+
+// ---- reverse ----
+__global__ void hk_b_a1(int N, int h2, const float* __restrict__ a1b, const float* __restrict__ wb1, float stdv,
+                        float* __restrict__ g_a1) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)N * h2) return;
+  const int c = (int)(gid % h2);
+  g_a1[gid] = stdv * wb1[c] * dsilu_f(a1b[gid]);
+}
+
+// g_p[s] = g_v * p[s] / v   (adjoint of the 2-norm over s; 0 where v == 0 like torch.norm)
+__global__ void hk_b_norm_s(int N, int S, int C, const float* __restrict__ g_cat, int ldg, int goff,
+                            const float* __restrict__ cat, int ldc, int coff, const float* __restrict__ p, int ldp,
+                            float* __restrict__ g_p, int ldgp) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)N * C) return;
+  const int i = (int)(gid / C), c = (int)(gid % C);
+  const float v = cat[(size_t)i * ldc + coff + c];
+  const float g = g_cat[(size_t)i * ldg + goff + c];
+  const float sc = v > 0.f ? g / v : 0.f;
+  for (int s = 0; s < S; ++s) g_p[((size_t)i * S + s) * ldgp + c] = sc * p[((size_t)i * S + s) * ldp + c];
+}
+
+// g_gate = sum_s g_vec1o[s] v2[s] ; g_v2[s] = g_vec1o[s] gate ; g_xs = g_x1 silu'(xs)
+__global__ void hk_b_mid(int N, int S, int H, const float* __restrict__ u0, const float* __restrict__ pv0, int ldp,
+                         const float* __restrict__ g_vec1o, const float* __restrict__ g_cat1,
+                         float* __restrict__ g_u0, float* __restrict__ g_pv0) {
+  const int h2 = H / 2;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)N * h2) return;
+  const int i = (int)(gid / h2), c = (int)(gid % h2);
+  const float gate = u0[(size_t)i * H + h2 + c];
+  float gg = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float gv = g_vec1o[((size_t)i * S + s) * h2 + c];
+    gg += gv * pv0[((size_t)i * S + s) * ldp + H + c];
+    g_pv0[((size_t)i * S + s) * ldp + H + c] = gv * gate;
+  }
+  g_u0[(size_t)i * H + c] = g_cat1[(size_t)i * H + c] * dsilu_f(u0[(size_t)i * H + c]);
+  g_u0[(size_t)i * H + h2 + c] = gg;
+}
+
+__global__ void hk_b_mul_dsilu(long long n, const float* __restrict__ a, float* __restrict__ g) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n) return;
+  g[gid] *= dsilu_f(a[gid]);
+}
+
+static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, const float* vo,
+                        const int* fstart, const int* fend, int B, float* e_out) {
+  const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
+  if (N <= 0) {
+    if (B > 0) hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out);
+    return 0;
+  }
+  int rc = 0;
+  rc |= launch_gemm(st, vo, H, W.Wpv0, H, Bf.pv0, ldp, nullptr, N * S, nullptr, ldp, H, 0);
+  hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * H)), dim3(256), 0, st, N, S, H, Bf.pv0, ldp, Bf.cat0,
+                     2 * H, H);
+  rc |= launch_gemm(st, Bf.cat0, 2 * H, W.Wa0, 2 * H, Bf.a0, H, W.ba0, N, nullptr, H, 2 * H, 0);
+  rc |= launch_gemm(st, Bf.a0, H, W.Wb0, H, Bf.u0, H, W.bb0, N, nullptr, H, H, 2);
+  hipLaunchKernelGGL(hk_mid, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, Bf.u0, Bf.pv0, ldp, Bf.cat1,
+                     Bf.vec1o);
+  rc |= launch_gemm(st, Bf.vec1o, h2, W.W11, h2, Bf.p1, h2, nullptr, N * S, nullptr, h2, h2, 0);
+  hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.p1, h2, Bf.cat1, H,
+                     h2);
+  rc |= launch_gemm(st, Bf.cat1, H, W.Wa1, H, Bf.a1b, h2, W.ba1, N, nullptr, h2, H, 0);
+  hipLaunchKernelGGL(hk_final, dim3(nblk(N)), dim3(256), 0, st, N, h2, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
+                     D.zi, Bf.y);
+  hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out);
+  return rc;
+}
+
+// leaves dE/d(out_norm(x)) in Bf.g_cat0[:, :H] (row stride 2H) and dE/d(vec_out_norm(vec)) in g_vo
+int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, float* g_vo) {
+  const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
+  if (N <= 0) return 0;
+  int rc = 0;
+  hipLaunchKernelGGL(hk_b_a1, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, h2, Bf.a1b, W.wb1, W.stdv,
+                     Bf.g_a1);
+  rc |= launch_gemm(st, Bf.g_a1, h2, W.Wa1T, h2, Bf.g_cat1, H, nullptr, N, nullptr, H, h2, 0);
+  hipLaunchKernelGGL(hk_b_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.g_cat1, H, h2,
+                     Bf.cat1, H, h2, Bf.p1, h2, Bf.g_p1, h2);
+  rc |= launch_gemm(st, Bf.g_p1, h2, W.W11T, h2, Bf.g_vec1o, h2, nullptr, N * S, nullptr, h2, h2, 0);
+  hipLaunchKernelGGL(hk_b_mid, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, Bf.u0, Bf.pv0, ldp,
+                     Bf.g_vec1o, Bf.g_cat1, Bf.g_u0, Bf.g_pv0);
+  rc |= launch_gemm(st, Bf.g_u0, H, W.Wb0T, H, Bf.g_h0, H, nullptr, N, nullptr, H, H, 0);
+  hipLaunchKernelGGL(hk_b_mul_dsilu, dim3(nblk((long long)N * H)), dim3(256), 0, st, (long long)N * H, Bf.a0,
+                     Bf.g_h0);
+  rc |= launch_gemm(st, Bf.g_h0, H, W.Wa0T, H, Bf.g_cat0, 2 * H, nullptr, N, nullptr, 2 * H, H, 0);
+  hipLaunchKernelGGL(hk_b_norm_s, dim3(nblk((long long)N * H)), dim3(256), 0, st, N, S, H, Bf.g_cat0, 2 * H, H,
+                     Bf.cat0, 2 * H, H, Bf.pv0, ldp, Bf.g_pv0, ldp);
+  rc |= launch_gemm(st, Bf.g_pv0, ldp, W.Wpv0T, ldp, g_vo, H, nullptr, N * S, nullptr, H, ldp, 0);
+  return rc;
+}
+
+// ---- overlap-force recombination (Calculators/combiner.py:38-39) ----------------
+// f_prot[a] = sum_{k in [off[a], off[a+1])} sign[k] * f_frag[rows[k]]   (fixed order)
+__global__ void k_combine(int n_prot, const int* __restrict__ off, const int* __restrict__ rows,
+                          const float* __restrict__ sign, const float* __restrict__ f_frag,
+                          float* __restrict__ f_prot) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_prot) return;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  for (int k = off[a]; k < off[a + 1]; ++k) {
+    const float s = sign[k];
+    const size_t r = (size_t)rows[k] * 3;
+    fx += s * f_frag[r + 0];
+    fy += s * f_frag[r + 1];
+    fz += s * f_frag[r + 2];
+  }
+  f_prot[3 * (size_t)a + 0] = fx;
+  f_prot[3 * (size_t)a + 1] = fy;
+  f_prot[3 * (size_t)a + 2] = fz;
+}
+
+int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
+                   const float* f_frag, float* f_prot) {
+  if (n_prot <= 0) return 0;
+  hipLaunchKernelGGL(k_combine, dim3(nblk(n_prot)), dim3(256), 0, st, n_prot, off, rows, sign, f_frag, f_prot);
+  return 0;
+}
+
+}  // namespace vsn

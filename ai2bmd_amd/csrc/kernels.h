@@ -1,0 +1,111 @@
+// Host-side launch interface between the engine (engine.cpp) and the kernel
+// translation units.  All pointers are device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsn {
+
+struct GraphArgs {
+  const float* pos;
+  const long long* z64;
+  const int* fstart;
+  const int* fend;
+  int B, N, Emax, max_frag;
+  float rc, rc2, alpha;
+  int max_nb, R, Rp, S;
+  const float* means;
+  const float* betas;
+  int* deg;
+  int* zi;
+  int* rowptr;
+  int* colptr;
+  int* src;
+  int* tgt;
+  int* perm;
+  int* ecount;
+  float* geo;   // [E,8]  r, C, dC, ux, uy, uz, 1/r, 0
+  float* d;     // [E,8]  spherical harmonics (first S used)
+  float* rbf;   // [E,Rp]
+  float* drbf;  // [E,Rp]
+};
+
+// Everything the per-layer kernels need (one chunk).
+struct Dims {
+  int N, Emax, H, S, nh, R, Rp;
+  const int* ecount;
+  const int* rowptr;
+  const int* colptr;
+  const int* src;
+  const int* tgt;
+  const int* perm;
+  const int* zi;
+  const float* geo;
+  const float* d;
+};
+
+int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
+                const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
+int launch_transpose(hipStream_t st, const float* in, float* out, int rows, int cols);
+
+int launch_graph(hipStream_t st, const GraphArgs& a);
+int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
+                    float* f_out);
+
+// ---- forward ----
+int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
+                      float* cat);
+int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec);
+int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
+                     const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
+                     int ldxh, float* vh);
+int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A);
+int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
+                       const float* o, float* x, float* vec);
+int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f);
+
+// ---- reverse ----
+int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, const float* g_vec, const float* vp,
+                           const float* o, float* g_o, float* g_vp);
+int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
+                           float* g_pe, float* g_vp, float* g_geo);
+int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
+                      float* g_t, float* g_vh, float* g_geo);
+int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
+                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo);
+int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh, const float* xn,
+                         const float* rstd, const float* gamma, const float* wvec, int norm_type, int accumulate,
+                         float* g_x, float* g_vec);
+int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
+                          float* g_pp, float* g_x);
+int launch_bwd_embed_node(hipStream_t st, const Dims& D, const float* emb2, const float* pp, const float* g_n,
+                          float* g_pp, float* g_geo);
+
+// ---- read-out head ----
+struct HeadW {
+  const float *Wpv0, *Wpv0T;  // [H+h2,H], [H,H+h2]
+  const float *Wa0, *ba0, *Wa0T;
+  const float *Wb0, *bb0, *Wb0T;
+  const float *W11, *W11T;
+  const float *Wa1, *ba1, *Wa1T;
+  const float* wb1;  // [h2] row 0 of update_net.2 of block 1
+  float bb1, mean, stdv;
+  const float* atomref;  // [Z] or null
+};
+struct HeadBuf {
+  float *cat0, *pv0, *a0, *u0, *vec1o, *cat1, *p1, *a1b, *y;        // forward
+  float *g_a1, *g_cat1, *g_p1, *g_vec1o, *g_u0, *g_h0, *g_cat0, *g_pv0;  // reverse
+};
+// expects out_norm(x) already in Bf.cat0[:, :H] (row stride 2H)
+int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, const float* vo,
+                        const int* fstart, const int* fend, int B, float* e_out);
+// leaves dE/d out_norm(x) in Bf.g_cat0[:, :H] (row stride 2H), dE/d vec_out_norm(vec) in g_vo
+int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, float* g_vo);
+
+int launch_fill(hipStream_t st, float* p, size_t n, float v);
+
+// ---- combine (Calculators/combiner.py:24-41) ----
+int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
+                   const float* f_frag, float* f_prot);
+
+}  // namespace vsn

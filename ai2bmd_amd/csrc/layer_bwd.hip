@@ -1,0 +1,575 @@
+// Reverse-pass (input-gradient only) kernels of the ViS-MP layers and embeddings.
+//
+// The reference obtains forces with torch.autograd.grad(E, pos)
+// (ViSNet/model/visnet.py:153-165) with every parameter frozen (visnet.py:89-90),
+// so only input gradients are ever needed.  These kernels are the hand-derived
+// adjoints of layer_fwd.hip (derivation checked against autograd in
+// oracle/visnet_oracle.py::energy_forces_analytic, same staging and names).
+//
+// Positions enter the network only through per-edge r (rbf, cutoff) and the
+// spherical harmonics d[S]; every kernel here adds its share of dE/dd and
+// dE/dC into g_geo[E,16] (d at 0..S-1, C at 8); graph.hip::k_bwd_geom folds them
+// into forces once at the end.
+//
+// Sums over a node's IN-edges ("T" kernels, CSR by target) and over its
+// OUT-edges ("S" kernels, perm/colptr by source) are register accumulations by
+// one wave per node in a fixed order - no atomics, bit-reproducible.
+#include "common.h"
+#include "kernels.h"
+
+namespace vsn {
+
+#define VSN_DISPATCH_VS(H_, S_, FN, ...)                                 \
+  do {                                                                   \
+    const int v__ = (H_) / 64;                                           \
+    if ((S_) == 8) {                                                     \
+      if (v__ == 4) FN<4, 8> __VA_ARGS__;                                \
+      else if (v__ == 2) FN<2, 8> __VA_ARGS__;                           \
+      else if (v__ == 1) FN<1, 8> __VA_ARGS__;                           \
+      else return -22;                                                   \
+    } else if ((S_) == 3) {                                              \
+      if (v__ == 4) FN<4, 3> __VA_ARGS__;                                \
+      else if (v__ == 2) FN<2, 3> __VA_ARGS__;                           \
+      else if (v__ == 1) FN<1, 3> __VA_ARGS__;                           \
+      else return -22;                                                   \
+    } else return -22;                                                   \
+  } while (0)
+
+static inline int node_grid(int N) {
+  int g = (N + 3) / 4;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// ---- adjoint of the node update (visnet_block.py:271-274) ------------------------
+// g_o = [sum_s g_vec*vec3 | g_x*vec_dot | g_x] ; g_vp = [g_vdot*vec2 | g_vdot*vec1 | g_vec*o1]
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __restrict__ g_x,
+                                                         const float* __restrict__ g_vec,
+                                                         const float* __restrict__ vp, const float* __restrict__ o,
+                                                         float* __restrict__ g_o, float* __restrict__ g_vp) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    float gx[V], o1[V], o2[V], gvd[V], vd[V], go1[V];
+    ldrow<V>(g_x + (size_t)i * H, lane, gx);
+    ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+    ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      gvd[c] = gx[c] * o2[c];
+      vd[c] = 0.f;
+      go1[c] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float* row = vp + ((size_t)i * S + s) * 5 * H;
+      float* grow = g_vp + ((size_t)i * S + s) * 5 * H;
+      float v1[V], v2[V], v3[V], gv[V], t1[V], t2[V], t3[V];
+      ldrow<V>(row, lane, v1);
+      ldrow<V>(row + H, lane, v2);
+      ldrow<V>(row + 2 * H, lane, v3);
+      ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        vd[c] += v1[c] * v2[c];
+        go1[c] += gv[c] * v3[c];
+        t1[c] = gvd[c] * v2[c];
+        t2[c] = gvd[c] * v1[c];
+        t3[c] = gv[c] * o1[c];
+      }
+      strow<V>(grow, lane, t1);
+      strow<V>(grow + H, lane, t2);
+      strow<V>(grow + 2 * H, lane, t3);
+    }
+    float go2[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) go2[c] = gx[c] * vd[c];
+    strow<V>(g_o + (size_t)i * 3 * H, lane, go1);
+    strow<V>(g_o + (size_t)i * 3 * H + H, lane, go2);
+    strow<V>(g_o + (size_t)i * 3 * H + 2 * H, lane, gx);
+  }
+}
+
+// ---- adjoint of the edge update, target side --------------------------------------
+// wd = u1.u2 + a1 a2 cc ; df = silu(pf) wd
+// g_pf = g_f wd silu'(pf) ; g_wd = g_f silu(pf)
+// g_wt_i = sum_e g_wd (u2 + a2 cc d) ; g_d += sum_c g_wd (cc (a2 u1 + a1 u2) + 2 a1 a2 d)
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_edge_update_T(Dims D, const float* __restrict__ vp,
+                                                           const float* __restrict__ pe,
+                                                           const float* __restrict__ g_f, float* __restrict__ g_pe,
+                                                           float* __restrict__ g_vp, float* __restrict__ g_geo) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float wt[S][V], gwt[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, wt[s]);
+#pragma unroll
+      for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
+    }
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float u2[S][V], dd[S];
+      float dot[V], a1[V], a2[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) dot[c] = a1[c] = a2[c] = 0.f;
+      float cc = -2.0f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        ldrow<V>(vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, u2[s]);
+        dd[s] = D.d[(size_t)e * 8 + s];
+        cc += dd[s] * dd[s];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          dot[c] += wt[s][c] * u2[s][c];
+          a1[c] += wt[s][c] * dd[s];
+          a2[c] += u2[s][c] * dd[s];
+        }
+      }
+      float pf[V], gf[V], gpf[V], gwd[V];
+      ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
+      ldrow<V>(g_f + (size_t)e * H, lane, gf);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        float sp, dsp;
+        silu_both(pf[c], sp, dsp);
+        const float wd = dot[c] + a1[c] * a2[c] * cc;
+        gpf[c] = gf[c] * wd * dsp;
+        gwd[c] = gf[c] * sp;
+      }
+      strow<V>(g_pe + (size_t)e * 3 * H + 2 * H, lane, gpf);
+      float mine = 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float p = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          gwt[s][c] += gwd[c] * (u2[s][c] + a2[c] * cc * dd[s]);
+          p += gwd[c] * (cc * (a2[c] * wt[s][c] + a1[c] * u2[s][c]) + 2.0f * a1[c] * a2[c] * dd[s]);
+        }
+        p = wave_sum(p);
+        if (lane == s) mine = p;
+      }
+      if (lane < S) g_geo[(size_t)e * 16 + lane] += mine;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, gwt[s]);
+  }
+}
+
+// ---- adjoint of the edge update, source side: g_ws_j = sum_{e: src=j} g_wd (u1 + a1 cc d) ----
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_edge_update_S(Dims D, const float* __restrict__ vp,
+                                                           const float* __restrict__ pe,
+                                                           const float* __restrict__ g_f,
+                                                           float* __restrict__ g_vp) {
+  const int H = D.H;
+  VSN_NODE_LOOP(j, D.N) {
+    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    float gws[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < V; ++c) gws[s][c] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const int e = uni(D.perm[t]);
+      const int i = uni(D.tgt[e]);
+      float u1[S][V], dd[S], a1[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) a1[c] = 0.f;
+      float cc = -2.0f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, u1[s]);
+        dd[s] = D.d[(size_t)e * 8 + s];
+        cc += dd[s] * dd[s];
+#pragma unroll
+        for (int c = 0; c < V; ++c) a1[c] += u1[s][c] * dd[s];
+      }
+      float pf[V], gf[V], gwd[V];
+      ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
+      ldrow<V>(g_f + (size_t)e * H, lane, gf);
+#pragma unroll
+      for (int c = 0; c < V; ++c) gwd[c] = gf[c] * silu_f(pf[c]);
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int c = 0; c < V; ++c) gws[s][c] += gwd[c] * (u1[s][c] + a1[c] * cc * dd[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
+  }
+}
+
+// ---- adjoint of the vector messages, target side -----------------------------------
+// mv_e[s] = vh_j[s] s1 + d_s s2 ; g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_s
+// g_t = [g_s1 silu'(t1) | g_s2 silu'(t2)] ; g_d[s] += sum_c g_vec_i[s] s2
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_vecmsg_T(Dims D, const float* __restrict__ g_vec,
+                                                      const float* __restrict__ vh, const float* __restrict__ tpre,
+                                                      float* __restrict__ g_t, float* __restrict__ g_geo) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float gv[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float t1[V], t2[V], s2[V], d1[V], d2[V];
+      ldrow<V>(tpre + (size_t)e * 2 * H, lane, t1);
+      ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        d1[c] = dsilu_f(t1[c]);
+        silu_both(t2[c], s2[c], d2[c]);
+      }
+      float gs1[V], gs2[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) gs1[c] = gs2[c] = 0.f;
+      float mine = 0.f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float vj[V];
+        ldrow<V>(vh + ((size_t)j * S + s) * H, lane, vj);
+        const float ds = D.d[(size_t)e * 8 + s];
+        float p = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          gs1[c] += gv[s][c] * vj[c];
+          gs2[c] += gv[s][c] * ds;
+          p += gv[s][c] * s2[c];
+        }
+        p = wave_sum(p);
+        if (lane == s) mine = p;
+      }
+      if (lane < S) g_geo[(size_t)e * 16 + lane] += mine;
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        gs1[c] *= d1[c];
+        gs2[c] *= d2[c];
+      }
+      strow<V>(g_t + (size_t)e * 2 * H, lane, gs1);
+      strow<V>(g_t + (size_t)e * 2 * H + H, lane, gs2);
+    }
+  }
+}
+
+// ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_vecmsg_S(Dims D, const float* __restrict__ g_vec,
+                                                      const float* __restrict__ tpre, float* __restrict__ g_vh) {
+  const int H = D.H;
+  VSN_NODE_LOOP(j, D.N) {
+    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    float acc[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[s][c] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const int e = uni(D.perm[t]);
+      const int i = uni(D.tgt[e]);
+      float s1[V];
+      ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
+#pragma unroll
+      for (int c = 0; c < V; ++c) s1[c] = silu_f(s1[c]);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float gv[V];
+        ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv);
+#pragma unroll
+        for (int c = 0; c < V; ++c) acc[s][c] += gv[c] * s1[c];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
+  }
+}
+
+// ---- adjoint of attention / scalar message, target side ---------------------------
+// gm = g_m_e + g_A_i (overwrites g_m) ; recompute sat, a
+// g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a silu'(sat) C ; g_C += sum_h g_a silu(sat)
+// g_pk = g_sat q_i k_j silu'(pk) ; g_pv = gm v_j a silu'(pv) ; g_q_i = sum_e g_sat k_j dk
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_attn_T(Dims D, const float* __restrict__ qkv,
+                                                    const float* __restrict__ pe, const float* __restrict__ g_A,
+                                                    float* __restrict__ g_m, float* __restrict__ g_pe,
+                                                    float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
+                                                    float* __restrict__ g_geo) {
+  const int H = D.H;
+  const int nh = D.nh;
+  const int lph = 64 / nh;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float q[V], gA[V], gq[V];
+    ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
+    ldrow<V>(g_A + (size_t)i * H, lane, gA);
+#pragma unroll
+    for (int c = 0; c < V; ++c) gq[c] = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      const float C = D.geo[(size_t)e * 8 + 1];
+      float k[V], v[V], pk[V], pv[V], gm[V];
+      ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
+      ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
+      ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
+      ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
+      ldrow<V>(g_m + (size_t)e * H, lane, gm);
+      float dk[V], ddk[V], dv[V], ddv[V];
+      float part = 0.f, gpart = 0.f;
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        gm[c] += gA[c];
+        silu_both(pk[c], dk[c], ddk[c]);
+        silu_both(pv[c], dv[c], ddv[c]);
+        part += q[c] * k[c] * dk[c];
+        gpart += gm[c] * v[c] * dv[c];
+      }
+      strow<V>(g_m + (size_t)e * H, lane, gm);
+      const float sat = group_sum(part, lph);
+      const float ga = group_sum(gpart, lph);
+      float ssat, dssat;
+      silu_both(sat, ssat, dssat);
+      const float a = ssat * C;
+      const float gsat = ga * dssat * C;
+      const bool head_lead = (lane & (lph - 1)) == 0;
+      const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
+      if (lane == 0) g_geo[(size_t)e * 16 + 8] += gC;
+      if (head_lead) {
+        sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
+        sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
+      }
+      float gpk[V], gpv[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        gpk[c] = gsat * q[c] * k[c] * ddk[c];
+        gpv[c] = gm[c] * v[c] * a * ddv[c];
+        gq[c] += gsat * k[c] * dk[c];
+      }
+      strow<V>(g_pe + (size_t)e * 3 * H, lane, gpk);
+      strow<V>(g_pe + (size_t)e * 3 * H + H, lane, gpv);
+    }
+    strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq);
+  }
+}
+
+// ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_attn_S(Dims D, const float* __restrict__ qkv,
+                                                    const float* __restrict__ pe, const float* __restrict__ g_m,
+                                                    const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
+  const int H = D.H;
+  const int nh = D.nh;
+  const int lph = 64 / nh;
+  VSN_NODE_LOOP(j, D.N) {
+    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    float gk[V], gv[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) gk[c] = gv[c] = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const int e = uni(D.perm[t]);
+      const int i = uni(D.tgt[e]);
+      float q[V], pk[V], pv[V], gm[V];
+      ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
+      ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
+      ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
+      ldrow<V>(g_m + (size_t)e * H, lane, gm);
+      const float gsat = sat_tmp[(size_t)e * 2 * nh + lane / lph];
+      const float a = sat_tmp[(size_t)e * 2 * nh + nh + lane / lph];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        gk[c] += gsat * q[c] * silu_f(pk[c]);
+        gv[c] += gm[c] * silu_f(pv[c]) * a;
+      }
+    }
+    strow<V>(g_qkv + (size_t)j * 3 * H + H, lane, gk);
+    strow<V>(g_qkv + (size_t)j * 3 * H + 2 * H, lane, gv);
+  }
+}
+
+// ---- adjoint of LayerNorm + VecLayerNorm("none") ------------------------------------
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __restrict__ g_xh, int ldg,
+                                                       const float* __restrict__ g_vh,
+                                                       const float* __restrict__ xn, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ wvec, int accumulate,
+                                                       float* __restrict__ g_x, float* __restrict__ g_vec) {
+  const int H = D.H;
+  const float invH = 1.0f / (float)H;
+  VSN_NODE_LOOP(i, D.N) {
+    float g[V], n[V], ga[V], w[V];
+    ldrow<V>(g_xh + (size_t)i * ldg, lane, g);
+    ldrow<V>(xn + (size_t)i * H, lane, n);
+    ldrow<V>(gamma, lane, ga);
+    ldrow<V>(wvec, lane, w);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      g[c] *= ga[c];
+      s1 += g[c];
+      s2 += g[c] * n[c];
+    }
+    const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+    const float rs = rstd[i];
+    float out[V];
+    if (accumulate)
+      ldrow<V>(g_x + (size_t)i * H, lane, out);
+    else {
+#pragma unroll
+      for (int c = 0; c < V; ++c) out[c] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) out[c] += rs * (g[c] - m1 - n[c] * m2);
+    strow<V>(g_x + (size_t)i * H, lane, out);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float gv[V], o[V];
+      ldrow<V>(g_vh + ((size_t)i * S + s) * H, lane, gv);
+      if (accumulate)
+        ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, o);
+      else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) o[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) o[c] += gv[c] * w[c];
+      strow<V>(g_vec + ((size_t)i * S + s) * H, lane, o);
+    }
+  }
+}
+
+// ---- adjoint of EdgeEmbedding (utils.py:331-337) -----------------------------------
+// g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_embed_edge(Dims D, const float* __restrict__ x,
+                                                        const float* __restrict__ pp, const float* __restrict__ g_f,
+                                                        float* __restrict__ g_pp, float* __restrict__ g_x) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int t0 = uni(D.colptr[i]), t1 = uni(D.colptr[i + 1]);
+    float xi[V], acc[V];
+    ldrow<V>(x + (size_t)i * H, lane, xi);
+    ldrow<V>(g_x + (size_t)i * H, lane, acc);
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float xj[V], ps[V], gf[V], gp[V];
+      ldrow<V>(x + (size_t)j * H, lane, xj);
+      ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
+      ldrow<V>(g_f + (size_t)e * H, lane, gf);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        gp[c] = gf[c] * (xi[c] + xj[c]);
+        acc[c] += gf[c] * ps[c];
+      }
+      strow<V>(g_pp + (size_t)e * 2 * H + H, lane, gp);
+    }
+    for (int t = t0; t < t1; ++t) {
+      const int e = uni(D.perm[t]);
+      float ps[V], gf[V];
+      ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
+      ldrow<V>(g_f + (size_t)e * H, lane, gf);
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[c] += gf[c] * ps[c];
+    }
+    strow<V>(g_x + (size_t)i * H, lane, acc);
+  }
+}
+
+// ---- adjoint of NeighborEmbedding's aggregation (utils.py:296-317) -------------------
+// g_Wn = g_n_i emb2[z_j] (non-loop) ; g_phi = g_Wn C ; g_C += sum_c g_Wn phi
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_bwd_embed_node(Dims D, const float* __restrict__ emb2,
+                                                        const float* __restrict__ pp, const float* __restrict__ g_n,
+                                                        float* __restrict__ g_pp, float* __restrict__ g_geo) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float gn[V];
+    ldrow<V>(g_n + (size_t)i * H, lane, gn);
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float gph[V];
+      if (j == i) {
+#pragma unroll
+        for (int c = 0; c < V; ++c) gph[c] = 0.f;
+        strow<V>(g_pp + (size_t)e * 2 * H, lane, gph);
+        continue;
+      }
+      const float C = D.geo[(size_t)e * 8 + 1];
+      float em[V], ph[V];
+      ldrow<V>(emb2 + (size_t)uni(D.zi[j]) * H, lane, em);
+      ldrow<V>(pp + (size_t)e * 2 * H, lane, ph);
+      float p = 0.f;
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const float gW = gn[c] * em[c];
+        gph[c] = gW * C;
+        p += gW * ph[c];
+      }
+      strow<V>(g_pp + (size_t)e * 2 * H, lane, gph);
+      p = wave_sum(p);
+      if (lane == 0) g_geo[(size_t)e * 16 + 8] += p;
+    }
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------
+int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, const float* g_vec, const float* vp,
+                           const float* o, float* g_o, float* g_vp) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_node_update, <<<node_grid(D.N), 256, 0, st>>>(D, g_x, g_vec, vp, o, g_o, g_vp));
+  return 0;
+}
+int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
+                           float* g_pe, float* g_vp, float* g_geo) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_edge_update_T,
+                  <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo));
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_edge_update_S, <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, g_f, g_vp));
+  return 0;
+}
+int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
+                      float* g_t, float* g_vh, float* g_geo) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_vecmsg_T, <<<node_grid(D.N), 256, 0, st>>>(D, g_vec, vh, tpre, g_t, g_geo));
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_vecmsg_S, <<<node_grid(D.N), 256, 0, st>>>(D, g_vec, tpre, g_vh));
+  return 0;
+}
+int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
+                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_attn_T,
+                  <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo));
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_attn_S, <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, g_m, sat_tmp, g_qkv));
+  return 0;
+}
+int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh,
+                         const float* xn, const float* rstd, const float* gamma, const float* wvec, int norm_type,
+                         int accumulate, float* g_x, float* g_vec) {
+  if (D.N <= 0) return 0;
+  if (norm_type != 0) return -38;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_node_norm,
+                  <<<node_grid(D.N), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
+                                                   g_vec));
+  return 0;
+}
+int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
+                          float* g_pp, float* g_x) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_embed_edge, <<<node_grid(D.N), 256, 0, st>>>(D, x, pp, g_f, g_pp, g_x));
+  return 0;
+}
+int launch_bwd_embed_node(hipStream_t st, const Dims& D, const float* emb2, const float* pp, const float* g_n,
+                          float* g_pp, float* g_geo) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_bwd_embed_node, <<<node_grid(D.N), 256, 0, st>>>(D, emb2, pp, g_n, g_pp, g_geo));
+  return 0;
+}
+
+}  // namespace vsn

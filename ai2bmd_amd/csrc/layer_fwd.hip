@@ -1,0 +1,360 @@
+// Forward gather / scatter / vector-feature kernels of the ViS-MP layers.
+//
+// Pattern: one wave64 per TARGET node walks the node's in-edges (CSR by target);
+// every lane owns V = H/64 contiguous channels, so a row of H floats is one
+// fully coalesced 64-lane access (16 B/lane at H = 256).  Per-target state
+// (q_i, w_trg v_i, accumulators) lives in registers for the whole edge loop,
+// edge scalars (source index, d_ij, cutoff) come through the scalar path,
+// segment sums are register accumulations in a fixed order: no atomics, results
+// are bit-reproducible run to run.  The dense products between these kernels
+// run on the MFMA GEMM (gemm.hip).
+//
+// Reference: ViSNet/model/utils.py:296-317 (NeighborEmbedding), :331-341
+// (EdgeEmbedding); visnet_block.py:237-312 (ViS_MP.forward/message/aggregate/
+// edge_update), :206-209 (vector_rejection); utils.py:165-249 (VecLayerNorm).
+#include "common.h"
+#include "kernels.h"
+
+namespace vsn {
+
+#define VSN_DISPATCH_VS(H_, S_, FN, ...)                                 \
+  do {                                                                   \
+    const int v__ = (H_) / 64;                                           \
+    if ((S_) == 8) {                                                     \
+      if (v__ == 4) FN<4, 8> __VA_ARGS__;                                \
+      else if (v__ == 2) FN<2, 8> __VA_ARGS__;                           \
+      else if (v__ == 1) FN<1, 8> __VA_ARGS__;                           \
+      else return -22;                                                   \
+    } else if ((S_) == 3) {                                              \
+      if (v__ == 4) FN<4, 3> __VA_ARGS__;                                \
+      else if (v__ == 2) FN<2, 3> __VA_ARGS__;                           \
+      else if (v__ == 1) FN<1, 3> __VA_ARGS__;                           \
+      else return -22;                                                   \
+    } else return -22;                                                   \
+  } while (0)
+
+static inline int node_grid(int N) {
+  int g = (N + 3) / 4;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return g;
+}
+
+// ---- embeddings -------------------------------------------------------------
+// cat[i] = [ emb1[z_i] | sum_{j->i, j!=i} emb2[z_j] * phi_e * C_e ]   (utils.py:296-317)
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_embed_node(Dims D, const float* __restrict__ emb1,
+                                                    const float* __restrict__ emb2, const float* __restrict__ pp,
+                                                    float* __restrict__ cat) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float acc[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) acc[c] = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      if (j == i) continue;
+      const float C = D.geo[(size_t)e * 8 + 1];
+      float em[V], ph[V];
+      ldrow<V>(emb2 + (size_t)uni(D.zi[j]) * H, lane, em);
+      ldrow<V>(pp + (size_t)e * 2 * H, lane, ph);
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[c] += em[c] * (ph[c] * C);
+    }
+    float x0[V];
+    ldrow<V>(emb1 + (size_t)uni(D.zi[i]) * H, lane, x0);
+    strow<V>(cat + (size_t)i * 2 * H, lane, x0);
+    strow<V>(cat + (size_t)i * 2 * H + H, lane, acc);
+  }
+}
+
+// f_e = (x_i + x_j) * psi_e for all edges incl. loops (utils.py:331-337); vec = 0
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_embed_edge(Dims D, const float* __restrict__ x,
+                                                    const float* __restrict__ pp, float* __restrict__ f,
+                                                    float* __restrict__ vec) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float xi[V];
+    ldrow<V>(x + (size_t)i * H, lane, xi);
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float xj[V], ps[V], o[V];
+      ldrow<V>(x + (size_t)j * H, lane, xj);
+      ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
+#pragma unroll
+      for (int c = 0; c < V; ++c) o[c] = (xi[c] + xj[c]) * ps[c];
+      strow<V>(f + (size_t)e * H, lane, o);
+    }
+    float zr[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) zr[c] = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) strow<V>(vec + ((size_t)i * S + s) * H, lane, zr);
+  }
+}
+
+// ---- LayerNorm + VecLayerNorm (visnet_block.py:238-239, utils.py:186-249) -----
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restrict__ x, const float* __restrict__ vec,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   const float* __restrict__ wvec, int norm_type,
+                                                   float* __restrict__ xn, float* __restrict__ rstd,
+                                                   float* __restrict__ xh, int ldxh, float* __restrict__ vh) {
+  const int H = D.H;
+  const float invH = 1.0f / (float)H;
+  VSN_NODE_LOOP(i, D.N) {
+    float xv[V], g[V], b[V], w[V];
+    ldrow<V>(x + (size_t)i * H, lane, xv);
+    ldrow<V>(gamma, lane, g);
+    ldrow<V>(beta, lane, b);
+    ldrow<V>(wvec, lane, w);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) s += xv[c];
+    const float mean = wave_sum(s) * invH;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      xv[c] -= mean;
+      q += xv[c] * xv[c];
+    }
+    const float var = wave_sum(q) * invH;
+    const float rs = 1.0f / sqrtf(var + 1e-5f);
+    float n[V], h[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      n[c] = xv[c] * rs;
+      h[c] = n[c] * g[c] + b[c];
+    }
+    strow<V>(xn + (size_t)i * H, lane, n);
+    strow<V>(xh + (size_t)i * ldxh, lane, h);
+    if (lane == 0) rstd[i] = rs;
+    // VecLayerNorm, norm_type 0 ("none"): vh = vec * weight
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx) {
+      float v[V];
+      ldrow<V>(vec + ((size_t)i * S + sidx) * H, lane, v);
+#pragma unroll
+      for (int c = 0; c < V; ++c) v[c] *= w[c];
+      strow<V>(vh + ((size_t)i * S + sidx) * H, lane, v);
+    }
+  }
+}
+
+// ---- attention + scalar message + its aggregation (visnet_block.py:276-283,305) --
+// a_h = silu(sum_c q_i k_j dk) * C ; m_e = v_j * dv * a ; A_i = sum_e m_e
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_edge_attn(Dims D, const float* __restrict__ qkv,
+                                                   const float* __restrict__ pe, float* __restrict__ m,
+                                                   float* __restrict__ A) {
+  const int H = D.H;
+  const int lph = 64 / D.nh;  // lanes per head
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float q[V], acc[V];
+    ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
+#pragma unroll
+    for (int c = 0; c < V; ++c) acc[c] = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      const float C = D.geo[(size_t)e * 8 + 1];
+      float k[V], v[V], pk[V], pv[V], mv[V];
+      ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
+      ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
+      ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
+      ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
+      float part = 0.f;
+#pragma unroll
+      for (int c = 0; c < V; ++c) part += q[c] * k[c] * silu_f(pk[c]);
+      const float sat = group_sum(part, lph);
+      const float a = silu_f(sat) * C;
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        mv[c] = v[c] * silu_f(pv[c]) * a;
+        acc[c] += mv[c];
+      }
+      strow<V>(m + (size_t)e * H, lane, mv);
+    }
+    strow<V>(A + (size_t)i * H, lane, acc);
+  }
+}
+
+// ---- vector messages, their aggregation and the node update ---------------------
+// V_i[s] = sum_e vh_j[s]*s1_e + d_e[s]*s2_e ; dx = (sum_s vec1 vec2) o2 + o3 ;
+// dvec = vec3 o1 + V ; x += dx ; vec += dvec    (visnet_block.py:284-288,271-274,129-137)
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_node_update(Dims D, const float* __restrict__ tpre,
+                                                     const float* __restrict__ vh, const float* __restrict__ vp,
+                                                     const float* __restrict__ o, float* __restrict__ x,
+                                                     float* __restrict__ vec) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float Va[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int c = 0; c < V; ++c) Va[s][c] = 0.f;
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float s1[V], s2[V];
+      ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
+      ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, s2);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        s1[c] = silu_f(s1[c]);
+        s2[c] = silu_f(s2[c]);
+      }
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float vj[V];
+        ldrow<V>(vh + ((size_t)j * S + s) * H, lane, vj);
+        const float ds = D.d[(size_t)e * 8 + s];
+#pragma unroll
+        for (int c = 0; c < V; ++c) Va[s][c] += vj[c] * s1[c] + ds * s2[c];
+      }
+    }
+    float o1[V], o2[V], o3[V], vd[V];
+    ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+    ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+    ldrow<V>(o + (size_t)i * 3 * H + 2 * H, lane, o3);
+#pragma unroll
+    for (int c = 0; c < V; ++c) vd[c] = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const float* row = vp + ((size_t)i * S + s) * 5 * H;
+      float v1[V], v2[V], v3[V], vv[V];
+      ldrow<V>(row, lane, v1);
+      ldrow<V>(row + H, lane, v2);
+      ldrow<V>(row + 2 * H, lane, v3);
+      ldrow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        vd[c] += v1[c] * v2[c];
+        vv[c] += v3[c] * o1[c] + Va[s][c];
+      }
+      strow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
+    }
+    float xv[V];
+    ldrow<V>(x + (size_t)i * H, lane, xv);
+#pragma unroll
+    for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
+    strow<V>(x + (size_t)i * H, lane, xv);
+  }
+}
+
+// ---- edge update (visnet_block.py:290-295): f_e += silu(pf_e) * <rej(wt_i,d), rej(ws_j,d)> ---
+// <w1,w2> = u1.u2 + (u1.d)(u2.d)(|d|^2 - 2)   (expanded double rejection)
+template <int V, int S>
+__global__ __launch_bounds__(256) void k_edge_update(Dims D, const float* __restrict__ vp,
+                                                     const float* __restrict__ pe, float* __restrict__ f) {
+  const int H = D.H;
+  VSN_NODE_LOOP(i, D.N) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    float wt[S][V];
+#pragma unroll
+    for (int s = 0; s < S; ++s) ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, wt[s]);
+    for (int e = e0; e < e1; ++e) {
+      const int j = uni(D.src[e]);
+      float dot[V], a1[V], a2[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) dot[c] = a1[c] = a2[c] = 0.f;
+      float cc = -2.0f;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        float u2[V];
+        ldrow<V>(vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, u2);
+        const float ds = D.d[(size_t)e * 8 + s];
+        cc += ds * ds;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          dot[c] += wt[s][c] * u2[c];
+          a1[c] += wt[s][c] * ds;
+          a2[c] += u2[c] * ds;
+        }
+      }
+      float pf[V], fv[V];
+      ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
+      ldrow<V>(f + (size_t)e * H, lane, fv);
+#pragma unroll
+      for (int c = 0; c < V; ++c) fv[c] += silu_f(pf[c]) * (dot[c] + a1[c] * a2[c] * cc);
+      strow<V>(f + (size_t)e * H, lane, fv);
+    }
+  }
+}
+
+// ---- launchers -------------------------------------------------------------------
+int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
+                      float* cat) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_embed_node, <<<node_grid(D.N), 256, 0, st>>>(D, emb1, emb2, pp, cat));
+  return 0;
+}
+int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_embed_edge, <<<node_grid(D.N), 256, 0, st>>>(D, x, pp, f, vec));
+  return 0;
+}
+int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
+                     const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
+                     int ldxh, float* vh) {
+  if (D.N <= 0) return 0;
+  if (norm_type != 0) return -38;
+  VSN_DISPATCH_VS(D.H, D.S, k_node_norm,
+                  <<<node_grid(D.N), 256, 0, st>>>(D, x, vec, gamma, beta, wvec, norm_type, xn, rstd, xh, ldxh, vh));
+  return 0;
+}
+int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_edge_attn, <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, m, A));
+  return 0;
+}
+int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
+                       const float* o, float* x, float* vec) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_node_update, <<<node_grid(D.N), 256, 0, st>>>(D, tpre, vh, vp, o, x, vec));
+  return 0;
+}
+int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, k_edge_update, <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, f));
+  return 0;
+}
+
+__global__ void k_fill(float* __restrict__ p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+int launch_fill(hipStream_t st, float* p, size_t n, float v) {
+  if (n == 0) return 0;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+  return 0;
+}
+
+__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float t[32][33];
+  int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+    int r = r0 + k;
+    t[k][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  int orow = blockIdx.x * 32, ocol = r0 + threadIdx.x;
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+    int rr = orow + k;
+    if (rr < cols && ocol < rows) out[(size_t)rr * rows + ocol] = t[threadIdx.x][k];
+  }
+}
+int launch_transpose(hipStream_t st, const float* in, float* out, int rows, int cols) {
+  dim3 g((cols + 31) / 32, (rows + 31) / 32), b(32, 8);
+  hipLaunchKernelGGL(k_transpose, g, b, 0, st, in, out, rows, cols);
+  return 0;
+}
+
+}  // namespace vsn

@@ -1,0 +1,219 @@
+"""Drop-in replacements for the reference's ViSNet calculator seam
+(/root/reference/src/Calculators/visnet_calculator.py):
+
+    ViSNetModel            :22-75    in-process model, dl_potential_loader()
+    ViSNetCalculator       :121-155  ASE-style whole-molecule calculator
+    get_visnet_model       :184-204  factory used by DLBondedCalculator
+
+Same names, argument meaning and return shapes; the network itself is the
+hand-written HIP library behind include/vsn.h (no TorchScript, no autograd).
+PyTorch is used only to hold the weights / IO tensors in HBM and for streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+
+import numpy as np
+import torch
+
+from . import capi
+from .fragment import FragmentData
+
+
+def _as_numpy(v):
+    if isinstance(v, torch.Tensor):
+        return v.detach().cpu().numpy()
+    return np.asarray(v)
+
+
+class ViSNetEngine:
+    """Thin owner of one vsn_handle (one device, one stream)."""
+
+    def __init__(self, hparams: dict, state_dict: dict, device: str):
+        if not isinstance(device, str) or not device.startswith("cuda"):
+            raise RuntimeError(
+                f"device={device!r}: the MI355X ViSNet calculator runs on 'cuda:<k>' (ROCm) devices only; "
+                "there is no CPU path in this package"
+            )
+        self.device = torch.device(device)
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.hparams = dict(hparams)
+        L = capi.lib()
+        self._L = L
+        for key, ok in (("rbf_type", ("expnorm",)), ("activation", ("silu", "swish")),
+                        ("attn_activation", ("silu", "swish")), ("model", ("ViSNetBlock",)),
+                        ("output_model", ("Scalar",)), ("reduce_op", ("add",))):
+            if hparams.get(key, ok[0]) not in ok:
+                raise NotImplementedError(f"{key}={hparams.get(key)!r} is not built in the HIP path (supported: {ok})")
+        prior = hparams.get("prior_model")
+        if prior not in (None, "Atomref", False):
+            raise NotImplementedError(f"prior_model={prior!r}")
+        hp = capi.VsnHParams(
+            hidden=int(hparams["embedding_dimension"]),
+            num_layers=int(hparams["num_layers"]),
+            num_rbf=int(hparams["num_rbf"]),
+            num_heads=int(hparams["num_heads"]),
+            lmax=int(hparams["lmax"]),
+            max_z=int(hparams["max_z"]),
+            max_num_neighbors=int(hparams["max_num_neighbors"]),
+            vecnorm_type=capi.VECNORM[hparams["vecnorm_type"]],
+            has_atomref=1 if prior == "Atomref" else 0,
+            cutoff=float(hparams["cutoff"]),
+        )
+        self._h = C.c_void_p()
+        rc = L.vsn_create(C.byref(self._h), C.byref(hp), self.index)
+        self._check(rc)
+        # weights live in HBM as PyTorch-ROCm tensors; the library packs its own fused copies
+        self.weights = {}
+        for name, val in state_dict.items():
+            name = re.sub(r"^model\.", "", name)
+            if name == "prior_model.initial_atomref":
+                continue
+            t = torch.as_tensor(_as_numpy(val), dtype=torch.float32).contiguous().to(self.device)
+            self.weights[name] = t
+            shape = (C.c_int64 * max(t.dim(), 1))(*(list(t.shape) or [1]))
+            rc = L.vsn_load_weight(self._h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim())
+            self._check(rc)
+        torch.cuda.synchronize(self.device)
+        self._check(L.vsn_finalize(self._h))
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._L.vsn_last_error(self._h)
+            raise RuntimeError(f"vsn error {rc}: {msg.decode() if msg else ''}")
+
+    def set_option(self, key: str, value: int):
+        self._check(self._L.vsn_set_option(self._h, key.encode(), int(value)))
+
+    def forces_device(self, z: torch.Tensor, pos: torch.Tensor, start: np.ndarray, end: np.ndarray,
+                      e_out: torch.Tensor, f_out: torch.Tensor, stream=None):
+        """All tensors already in HBM; asynchronous on `stream` (torch stream or None=current)."""
+        assert z.dtype == torch.int64 and pos.dtype == torch.float32 and z.is_cuda and pos.is_cuda
+        assert pos.is_contiguous() and z.is_contiguous() and e_out.is_contiguous() and f_out.is_contiguous()
+        start = np.ascontiguousarray(start, dtype=np.int64)
+        end = np.ascontiguousarray(end, dtype=np.int64)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = self._L.vsn_forces(self._h, C.c_void_p(z.data_ptr()), C.c_void_p(pos.data_ptr()), capi.i64_ptr(start),
+                                capi.i64_ptr(end), int(z.numel()), int(len(start)), C.c_void_p(e_out.data_ptr()),
+                                C.c_void_p(f_out.data_ptr()), C.c_void_p(st.cuda_stream))
+        self._check(rc)
+
+    def last_num_edges(self) -> int:
+        return int(self._L.vsn_last_num_edges(self._h))
+
+    def debug_read(self, name: str, layer: int = 0, dtype=np.float32, max_elems: int = 1 << 28) -> np.ndarray:
+        # size query by reading into a generously sized buffer
+        buf = np.empty(max_elems, dtype=dtype)
+        n = self._L.vsn_debug_read(self._h, name.encode(), int(layer), C.c_void_p(buf.ctypes.data), int(max_elems))
+        if n < 0:
+            self._check(int(n))
+        return buf[:n].copy()
+
+    def gemm(self, A, Bt, C_out, bias=None, flags=0, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        M, K = A.shape
+        Nc = Bt.shape[0]
+        rc = self._L.vsn_gemm(self._h, C.c_void_p(A.data_ptr()), A.stride(0), C.c_void_p(Bt.data_ptr()),
+                              Bt.stride(0), C.c_void_p(C_out.data_ptr()), C_out.stride(0),
+                              C.c_void_p(bias.data_ptr() if bias is not None else 0), M, Nc, K, flags,
+                              C.c_void_p(st.cuda_stream))
+        self._check(rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.vsn_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def load_checkpoint(filepath):
+    """Reads a Lightning-style checkpoint the way load_model does
+    (ViSNet/model/visnet.py:73-87): hyper-parameters from the file itself,
+    'model.' prefix stripped from the state_dict keys."""
+    ckpt = torch.load(filepath, map_location="cpu", weights_only=False)
+    hp = ckpt["hyper_parameters"]
+    sd = {re.sub(r"^model\.", "", k): v for k, v in ckpt["state_dict"].items()}
+    return hp, sd
+
+
+class ViSNetModel:
+    r"""Energy and forces of a fragment batch from the ViSNet potential
+    (mirror of Calculators/visnet_calculator.py:22-75)."""
+
+    implemented_properties = ["energy", "forces"]
+
+    def __init__(self, hparams, state_dict, device="cuda:0"):
+        self.device = device
+        self.engine = ViSNetEngine(hparams, state_dict, device)
+        self.stream = torch.cuda.Stream(device=device)
+
+    def collate(self, frag: FragmentData):
+        z = torch.as_tensor(np.ascontiguousarray(frag.z, dtype=np.int64)).to(self.device, non_blocking=True)
+        pos = torch.as_tensor(np.ascontiguousarray(frag.pos, dtype=np.float32)).to(self.device, non_blocking=True)
+        return dict(z=z, pos=pos, start=np.asarray(frag.start, dtype=np.int64),
+                    end=np.asarray(frag.end, dtype=np.int64))
+
+    def dl_potential_loader(self, frag_data: FragmentData):
+        """-> (e float32 [B_nonempty, 1], f float32 [N, 3]) as numpy, like the reference (:54-63)."""
+        with torch.cuda.stream(self.stream):
+            d = self.collate(frag_data)
+            B = len(d["start"])
+            N = int(d["z"].numel())
+            e = torch.empty(B, dtype=torch.float32, device=self.device)
+            f = torch.empty(N, 3, dtype=torch.float32, device=self.device)
+            self.engine.forces_device(d["z"], d["pos"], d["start"], d["end"], e, f, stream=self.stream)
+            nonempty = torch.as_tensor((d["end"] - d["start"]) > 0)
+            e_np = e.cpu()[nonempty].reshape(-1, 1).numpy()
+            f_np = f.cpu().reshape(-1, 3).numpy()
+        return e_np, f_np
+
+    @classmethod
+    def from_file(cls, **kwargs):
+        if "model_path" not in kwargs:
+            raise ValueError("model_path must be provided")
+        hp, sd = load_checkpoint(kwargs["model_path"])
+        return cls(hp, sd, device=kwargs.get("device", "cuda:0"))
+
+
+class ViSNetCalculator:
+    r"""Whole-molecule mode (`--mode visnet`): one fragment = the whole system
+    (mirror of Calculators/visnet_calculator.py:121-155; ASE's Calculator base is
+    not available here, so this class implements the same `calculate(atoms,
+    properties, system_changes)` / `.results` protocol stand-alone)."""
+
+    implemented_properties = ["energy", "forces"]
+
+    def __init__(self, model: ViSNetModel):
+        self.model = model
+        self.results = {}
+
+    def calculate(self, atoms, properties=("energy", "forces"), system_changes=None):
+        n = len(atoms)
+        data = FragmentData(
+            np.asarray(atoms.numbers),
+            np.asarray(atoms.positions, dtype=np.float32),
+            np.array([0], dtype=np.int64),
+            np.array([n], dtype=np.int64),
+            np.zeros((n,), dtype=np.int64),
+        )
+        e, f = self.model.dl_potential_loader(data)
+        self.results = {"energy": e, "forces": f}
+
+
+_local_calc: dict = {}
+
+
+def get_visnet_model(model_path: str, device: str):
+    """Factory with the reference's signature (:184-204).  The reference keeps one
+    GPU model in the master process and spawns pickle-over-socket workers for the
+    other GPUs; here every 'cuda:k' gets its own in-process handle (handles on
+    different devices run concurrently from different threads)."""
+    if device == "cpu":
+        raise RuntimeError("get_visnet_model(device='cpu'): this package is the MI355X path; no CPU model exists")
+    sig = f"{device}-{model_path}"
+    if sig not in _local_calc:
+        _local_calc[sig] = ViSNetModel.from_file(model_path=model_path, device=device)
+    return _local_calc[sig]

@@ -1,0 +1,122 @@
+/*
+ * vsn.h - C ABI of the MI355X-native ViSNet energy+force calculator.
+ *
+ * This is the drop-in boundary for AI2BMD's per-MD-step hot path.  Every entry
+ * point below replaces one interface of the reference (paths relative to
+ * /root/reference/src):
+ *
+ *   vsn_create / vsn_load_weight / vsn_finalize
+ *        <- ViSNet/model/visnet.py:73-93  load_model(): build the network from
+ *           ckpt["hyper_parameters"], load ckpt["state_dict"] (221 tensors at the
+ *           defaults, names listed in SURVEY.md 8a/a3), freeze, move to device.
+ *   vsn_forces
+ *        <- Calculators/visnet_calculator.py:54-63  ViSNetModel.dl_potential_loader
+ *           (= ViSNet.forward, ViSNet/model/visnet.py:135-166: radius graph,
+ *           RBF/SH, embeddings, L x ViS-MP, gated equivariant read-out,
+ *           per-fragment energy sum, F = -dE/dpos).
+ *   vsn_combine_plan_create / vsn_combine
+ *        <- Calculators/combiner.py:12-41  DipeptideBondedCombiner
+ *           (E = sum E_dip - sum E_ace ; F = scatter_sum(cat[F_dip,-F_ace][select], origin)).
+ *   vsn_partition
+ *        <- Calculators/device_strategy.py:84-127 _set_combined_work_partitions.
+ *
+ * Conventions: plain C types only; all `dev_*` pointers are HIP device
+ * pointers owned by the caller (e.g. PyTorch-ROCm tensors); `host_*` pointers
+ * are host memory.  Every function returns 0 on success or a negative code;
+ * vsn_last_error() gives the message (the Python host raises RuntimeError,
+ * matching the reference where exceptions propagate to the ASE caller).
+ * A handle is bound to one device and must not be used concurrently from two
+ * threads; different handles (different devices) may run concurrently, which is
+ * how DLBondedCalculator drives them (Calculators/bonded.py:75-77).
+ */
+#ifndef VSN_H
+#define VSN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vsn_ctx* vsn_handle;
+
+enum { VSN_VECNORM_NONE = 0, VSN_VECNORM_RMS = 1, VSN_VECNORM_MAXMIN = 2 };
+
+/* Hyper-parameters read by create_model (ViSNet/model/visnet.py:15-30). */
+typedef struct vsn_hparams {
+  int32_t hidden;            /* embedding_dimension (64 | 128 | 256)            */
+  int32_t num_layers;        /* num_layers                                     */
+  int32_t num_rbf;           /* num_rbf, expnorm basis                         */
+  int32_t num_heads;         /* power of two dividing 64                       */
+  int32_t lmax;              /* 1 | 2                                          */
+  int32_t max_z;             /* embedding rows                                 */
+  int32_t max_num_neighbors; /* radius_graph truncation (incl. the self loop)  */
+  int32_t vecnorm_type;      /* VSN_VECNORM_*                                  */
+  int32_t has_atomref;       /* prior_model == "Atomref"                       */
+  float cutoff;              /* Angstrom                                       */
+} vsn_hparams;
+
+int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id);
+void vsn_destroy(vsn_handle h);
+const char* vsn_last_error(vsn_handle h);
+
+/* Copies one state_dict tensor (reference key name without the "model."
+ * prefix) from `ptr` (device or host memory, fp32, C-contiguous). */
+int vsn_load_weight(vsn_handle h, const char* name, const void* ptr, const int64_t* shape, int ndim);
+/* Packs/transposes the loaded tensors into the kernels' layouts; fails if a
+ * required tensor is missing. */
+int vsn_finalize(vsn_handle h);
+
+/* Options: "max_chunk_edges" (workspace bound, default 262144),
+ * "use_graph" (1 = replay a captured hipGraph when shapes repeat). */
+int vsn_set_option(vsn_handle h, const char* key, int64_t value);
+
+/*
+ * Energy and forces of a batch of B fragments holding N atoms in total.
+ *   dev_z        int64 [N]    atomic numbers                (FragmentData.z)
+ *   dev_pos      f32   [N,3]  positions, Angstrom           (FragmentData.pos)
+ *   host_start   int64 [B]    first atom of each fragment   (FragmentData.start)
+ *   host_end     int64 [B]    one-past-last atom            (FragmentData.end)
+ *   dev_e_out    f32   [B]    per-fragment energy (empty fragments: `mean`)
+ *   dev_f_out    f32   [N,3]  forces = -dE/dpos
+ * Asynchronous on `stream` (a hipStream_t); outputs are valid once the stream
+ * has drained.  Fragments must be contiguous and ascending (start[b] == end[b-1]).
+ */
+int vsn_forces(vsn_handle h, const int64_t* dev_z, const float* dev_pos, const int64_t* host_start,
+               const int64_t* host_end, int64_t N, int64_t B, float* dev_e_out, float* dev_f_out, void* stream);
+
+/* Device-side edge count of the last chunk processed (synchronises). */
+int64_t vsn_last_num_edges(vsn_handle h);
+
+/* Debug/verification: copies a named internal buffer of the LAST chunk to host
+ * memory (synchronises).  Returns the number of floats (or int32s) written, or
+ * a negative code.  Names: see DESIGN.md "debug taps". */
+int64_t vsn_debug_read(vsn_handle h, const char* name, int layer, void* host_out, int64_t max_elems);
+
+/* Stand-alone GEMM tap used by the unit tests and the roofline bench:
+ * C[M,Nc] (+)= A[M,K] * Bt[Nc,K]^T (+ bias). flags: 1 = accumulate, 2 = silu(A). */
+int vsn_gemm(vsn_handle h, const float* dev_A, int lda, const float* dev_Bt, int ldb, float* dev_C, int ldc,
+             const float* dev_bias, int M, int Nc, int K, int flags, void* stream);
+
+/* ---- overlap-force recombination (Calculators/combiner.py:24-41) ---- */
+typedef struct vsn_combine_plan* vsn_combine_handle;
+/* select/origin as in forces_combine; `n_dip_rows` = rows of the dipeptide
+ * block in cat[F_dip, F_ace]; `host_row_of_cat[k]` maps row k of that
+ * concatenation to its row in the interleaved fragment-force array. */
+int vsn_combine_plan_create(vsn_combine_handle* out, int device_id, int64_t n_prot, int64_t n_cat,
+                            int64_t n_dip_rows, const int64_t* host_row_of_cat, const int64_t* host_select,
+                            const int64_t* host_origin, int64_t n_select);
+void vsn_combine_plan_destroy(vsn_combine_handle p);
+/* dev_f_frag f32 [n_cat,3] (interleaved order) -> dev_f_prot f32 [n_prot,3];
+ * dev_e_frag f32 [B] with host-provided sign per fragment folded into plan. */
+int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float* dev_f_prot, void* stream);
+
+/* ---- work partitions (Calculators/device_strategy.py:84-127) ---- */
+/* Writes up to max_out triples (device_idx, frag_begin, frag_end); returns count. */
+int vsn_partition(const int64_t* host_start, const int64_t* host_end, int64_t B, int n_devices,
+                  int64_t chunk_atoms, int64_t* out_triples, int max_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSN_H */

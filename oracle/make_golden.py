@@ -1,0 +1,77 @@
+"""TEST INFRASTRUCTURE ONLY - generates tests/golden/*.npz by running the
+REFERENCE's own ViSNet source (/root/reference/src/ViSNet/model, imported through
+oracle/ref_import.py + oracle/shims) on seeded weights and seeded inputs.
+
+Run in the build container only (the reference tree does not exist on the GPU
+box):   python -m oracle.make_golden
+Each fixture stores the inputs, the hyper-parameters, the weight seed and the
+reference's (E, F) in float64 (truth) and float32 (what the reference computes).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle.inputs import random_fragments  # noqa: E402
+from oracle.ref_import import import_reference_create_model  # noqa: E402
+from oracle.weights import default_hparams, make_state_dict  # noqa: E402
+
+CASES = {
+    # name: (hparam overrides, weight seed, input seed, fragment sizes)
+    "h64_l2": (dict(embedding_dimension=64, num_layers=2), 11, 101, [22, 12, 0, 30, 19]),
+    "h128_l3_lmax1": (dict(embedding_dimension=128, num_layers=3, lmax=1), 12, 102, [12, 26, 33]),
+    "h64_l2_trunc": (dict(embedding_dimension=64, num_layers=2, max_num_neighbors=16), 13, 103, [44, 36, 12]),
+    "h256_l9_default": (dict(), 14, 104, [22, 12, 28]),
+    "h64_l3_rms": (dict(embedding_dimension=64, num_layers=3, vecnorm_type="rms"), 15, 105, [24, 12]),
+    "h64_l3_maxmin": (dict(embedding_dimension=64, num_layers=3, vecnorm_type="max_min"), 16, 106, [24, 12]),
+    "h64_l2_whole": (dict(embedding_dimension=64, num_layers=2), 17, 107, [120]),
+}
+
+
+def run_reference(hp, sd, z, pos, start, end, dtype):
+    create_model = import_reference_create_model()
+    prev = torch.get_default_dtype()
+    try:
+        # utils.py:271 and visnet_block.py:119 allocate default-dtype zeros
+        torch.set_default_dtype(dtype)
+        model = create_model(hp)
+        model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+        model = model.to(dtype).eval()
+        for p in model.parameters():
+            p.requires_grad = False
+        sizes = end - start
+        batch = np.repeat(np.cumsum(sizes > 0) - 1, sizes)
+        E, F = model(dict(z=torch.as_tensor(z), pos=torch.as_tensor(pos).to(dtype), batch=torch.as_tensor(batch)))
+        return E.detach().numpy(), F.detach().numpy()
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def main():
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, (over, wseed, iseed, sizes) in CASES.items():
+        hp = default_hparams(**over)
+        sd = make_state_dict(hp, seed=wseed)
+        z, pos, start, end = random_fragments(iseed, sizes, cutoff=hp["cutoff"])
+        E64, F64 = run_reference(hp, sd, z, pos, start, end, torch.float64)
+        E32, F32 = run_reference(hp, sd, z, pos, start, end, torch.float32)
+        np.savez_compressed(
+            os.path.join(out_dir, f"visnet_{name}.npz"),
+            hparams=json.dumps(hp), weight_seed=wseed, z=z, pos=pos, start=start, end=end,
+            E_ref64=E64, F_ref64=F64, E_ref32=E32.astype(np.float32), F_ref32=F32.astype(np.float32),
+        )
+        print(f"{name}: N={len(z)} B={len(start)} |F|mean={np.abs(F64).mean():.4f} "
+              f"fp32-vs-fp64 dE={np.abs(E32 - E64).max():.2e} dF={np.abs(F32 - F64).max():.2e}")
+
+
+if __name__ == "__main__":
+    main()

@@ -394,6 +394,7 @@ class ViSNetOracle:
         g_x = layer_norm_vjp(g_xo, c["xon"], c["xorstd"], w[rm + "out_norm.weight"])
         g_vec = g_vo * w[rm + "vec_out_norm.weight"][None, None, :]
         b["g_x_L"], b["g_vec_L"] = g_x, g_vec
+        b["g_cat0"], b["g_vo"] = g_cat0, g_vo
 
         g_f = torch.zeros(E, H, dtype=dt)
         g_d = torch.zeros(E, S, dtype=dt)
@@ -488,7 +489,7 @@ class ViSNetOracle:
         g_phi = g_Wn * C[:, None]
         g_C += (g_Wn * c["phi"]).sum(-1)
         g_rbf = g_rbf + g_phi @ w[rm + "neighbor_embedding.distance_proj.weight"]
-        b.update(g_x_emb=g_xe, g_rbf=g_rbf, g_d=g_d, g_C=g_C)
+        b.update(g_x_emb=g_xe, g_rbf=g_rbf, g_d=g_d, g_C=g_C, g_n=g_n, g_phi=g_phi, g_psi=g_psi)
 
         # ---- geometry ----
         means = w[rm + "distance_expansion.means"]

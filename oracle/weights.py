@@ -53,10 +53,13 @@ def _xavier(rng, out_f, in_f):
     return rng.uniform(-a, a, size=(out_f, in_f)).astype(np.float32)
 
 
+BIAS_SCALE = 0.03  # keeps a 9-layer random network well conditioned while exercising every bias path
+
+
 def _bias(rng, n, trivial):
     if trivial:
         return np.zeros(n, np.float32)
-    return rng.uniform(-0.1, 0.1, size=n).astype(np.float32)
+    return rng.uniform(-BIAS_SCALE, BIAS_SCALE, size=n).astype(np.float32)
 
 
 def rbf_params(hp):

@@ -1,0 +1,37 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLDEN, f"visnet_{name}.npz"), allow_pickle=False)
+    out = {k: d[k] for k in d.files}
+    out["hparams"] = json.loads(str(out["hparams"]))
+    out["weight_seed"] = int(out["weight_seed"])
+    return out
+
+
+GOLDEN_CASES = ["h64_l2", "h128_l3_lmax1", "h64_l2_trunc", "h256_l9_default", "h64_l3_rms", "h64_l3_maxmin",
+                "h64_l2_whole"]
+# cases the HIP path supports today (vecnorm_type == "none")
+HIP_CASES = ["h64_l2", "h128_l3_lmax1", "h64_l2_trunc", "h256_l9_default", "h64_l2_whole"]
+
+
+@pytest.fixture(scope="session")
+def lib_built():
+    from ai2bmd_amd import build
+
+    return build.build()

@@ -1,0 +1,179 @@
+"""GPU parity proper: energies/forces of the HIP path (through the C ABI and the
+reference-shaped Python seam) against (i) the golden vectors produced by the
+reference's own source and (ii) the fp64 oracle on fresh seeded inputs.
+
+Tolerance (SURVEY.md 8c, fp32 contract, vs the fp64 truth):
+  per-fragment |dE| <= 1e-5 * max(1, |E|) ; force MAE <= 1e-5 * max(1, mean|F|) ;
+  max|dF| <= 1e-4 * max(1, max|F|)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import HIP_CASES, load_golden
+from oracle.inputs import random_fragments
+from oracle.visnet_oracle import ViSNetOracle
+from oracle.weights import default_hparams, make_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def check(E, F, E64, F64):
+    E, F = np.asarray(E, np.float64), np.asarray(F, np.float64)
+    assert E.shape == E64.shape and F.shape == F64.shape
+    assert np.isfinite(E).all() and np.isfinite(F).all()
+    de = np.abs(E - E64)
+    assert (de <= 1e-5 * np.maximum(1.0, np.abs(E64))).all(), f"dE max {de.max():.3e}"
+    mae = np.abs(F - F64).mean()
+    assert mae <= 1e-5 * max(1.0, np.abs(F64).mean()), f"force MAE {mae:.3e}"
+    mx = np.abs(F - F64).max()
+    assert mx <= 1e-4 * max(1.0, np.abs(F64).max()), f"force max err {mx:.3e}"
+
+
+def model_for(hp, seed):
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    return ViSNetModel(hp, make_state_dict(hp, seed=seed), device="cuda:0")
+
+
+def frag(z, pos, start, end):
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+
+    return FragmentData(z, pos, start, end, make_batch_index(start, end))
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_golden_reference_vectors(lib_built, name):
+    g = load_golden(name)
+    m = model_for(g["hparams"], g["weight_seed"])
+    e, f = m.dl_potential_loader(frag(g["z"], g["pos"], g["start"], g["end"]))
+    assert e.dtype == np.float32 and f.dtype == np.float32 and e.shape[1] == 1 and f.shape[1] == 3
+    check(e, f, g["E_ref64"], g["F_ref64"])
+    # and no worse than 4x the reference's own fp32 error (floor 2e-6 abs)
+    ref_err = max(np.abs(g["F_ref32"] - g["F_ref64"]).max(), 2e-6)
+    assert np.abs(f - g["F_ref64"]).max() <= 4 * ref_err + 1e-6 * np.abs(g["F_ref64"]).max()
+
+
+def test_fresh_seed_against_oracle_dipeptide_batch(lib_built):
+    hp = default_hparams(embedding_dimension=128, num_layers=4)
+    sizes = [22, 12, 28, 12, 0, 12, 36, 12, 19, 12, 33]
+    z, pos, start, end = random_fragments(2024, sizes)
+    sd = make_state_dict(hp, seed=77)
+    E64, F64, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    check(e, f, E64, F64)
+
+
+def test_run_to_run_bit_reproducible(lib_built):
+    g = load_golden("h64_l2")
+    m = model_for(g["hparams"], g["weight_seed"])
+    fd = frag(g["z"], g["pos"], g["start"], g["end"])
+    e1, f1 = m.dl_potential_loader(fd)
+    e2, f2 = m.dl_potential_loader(fd)
+    assert (e1 == e2).all() and (f1 == f2).all()
+
+
+def test_fragment_independence_and_chunking(lib_built):
+    """Fragments are independent units: evaluating a slice, or forcing the engine
+    to split the batch into several chunks, must give the same numbers."""
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    sizes = [22, 12, 30, 12, 26, 12, 19]
+    z, pos, start, end = random_fragments(9, sizes)
+    m = model_for(hp, 3)
+    fd = frag(z, pos, start, end)
+    e_all, f_all = m.dl_potential_loader(fd)
+    sub = fd[2:5]
+    e_sub, f_sub = m.dl_potential_loader(sub)
+    np.testing.assert_allclose(e_sub, e_all[2:5], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f_sub, f_all[start[2]:end[4]], rtol=0, atol=1e-5)
+    m.engine.set_option("max_chunk_edges", 1024)  # forces several chunks
+    e_ch, f_ch = m.dl_potential_loader(fd)
+    np.testing.assert_allclose(e_ch, e_all, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(f_ch, f_all, rtol=0, atol=1e-5)
+
+
+def test_translation_rotation_and_net_force(lib_built):
+    """Size-independent physics properties: E invariant and F equivariant under a
+    rigid motion; forces of every fragment sum to zero (E depends on differences only)."""
+    hp = default_hparams(embedding_dimension=64, num_layers=3)
+    z, pos, start, end = random_fragments(31, [24, 12, 33])
+    m = model_for(hp, 8)
+    e0, f0 = m.dl_potential_loader(frag(z, pos, start, end))
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    pos2 = (pos.astype(np.float64) @ Q.T + np.array([1.5, -2.0, 0.7])).astype(np.float32)
+    e1, f1 = m.dl_potential_loader(frag(z, pos2, start, end))
+    np.testing.assert_allclose(e1, e0, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(f1, f0 @ Q.T.astype(np.float32), rtol=0, atol=2e-4)
+    for s, e_ in zip(start, end):
+        assert np.abs(f0[s:e_].sum(0)).max() < 2e-4
+
+
+def test_large_batch_properties(lib_built):
+    """A batch big enough to need the 128x128 GEMM tiles and many workgroups:
+    replicated fragments must give replicated results (a checksum of checksums)."""
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    z1, p1, s1, e1 = random_fragments(5, [27, 12])
+    reps = 200
+    z = np.tile(z1, reps)
+    pos = np.concatenate([p1 + np.float32(0.0) for _ in range(reps)])
+    n1 = len(z1)
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    m = model_for(hp, 4)
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    e = e.reshape(reps, 2)
+    f = f.reshape(reps, n1, 3)
+    assert np.abs(e - e[0]).max() == 0.0
+    assert np.abs(f - f[0]).max() == 0.0
+    E64, F64, _ = ViSNetOracle(hp, make_state_dict(hp, seed=4), torch.float64).energy_forces(z1, p1, s1, e1)
+    check(e[0].reshape(-1, 1), f[0], E64, F64)
+
+
+def test_errors_are_loud(lib_built):
+    from ai2bmd_amd.visnet_calculator import ViSNetModel, get_visnet_model
+
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    with pytest.raises(RuntimeError):
+        ViSNetModel(hp, make_state_dict(hp, seed=1), device="cpu")
+    with pytest.raises(RuntimeError):
+        get_visnet_model("/nonexistent.ckpt", "cpu")
+    sd = make_state_dict(hp, seed=1)
+    sd.pop("representation_model.out_norm.weight")
+    with pytest.raises(RuntimeError, match="missing tensor"):
+        ViSNetModel(hp, sd, device="cuda:0")
+    m = model_for(hp, 1)
+    z, pos, start, end = random_fragments(1, [12, 12])
+    bad_start = start.copy()
+    bad_start[1] += 1
+    with pytest.raises(RuntimeError, match="contiguous"):
+        m.dl_potential_loader(frag(z, pos, bad_start, end))
+
+
+def test_checkpoint_file_roundtrip(lib_built, tmp_path):
+    """from_file reads the Lightning-shaped checkpoint the reference's load_model reads."""
+    from ai2bmd_amd.visnet_calculator import ViSNetCalculator, get_visnet_model
+    from oracle.weights import write_lightning_ckpt
+
+    g = load_golden("h64_l2_whole")
+    sd = make_state_dict(g["hparams"], seed=g["weight_seed"])
+    path = str(tmp_path / "visnet-uni-test.ckpt")
+    write_lightning_ckpt(path, g["hparams"], sd)
+    model = get_visnet_model(path, "cuda:0")
+    assert get_visnet_model(path, "cuda:0") is model
+
+    class Atoms:  # minimal ase.Atoms stand-in (ASE is not installed)
+        numbers = g["z"]
+        positions = g["pos"].astype(np.float64)
+
+        def __len__(self):
+            return len(self.numbers)
+
+    calc = ViSNetCalculator(model)
+    calc.calculate(Atoms(), ["energy", "forces"], None)
+    check(calc.results["energy"], calc.results["forces"], g["E_ref64"], g["F_ref64"])
