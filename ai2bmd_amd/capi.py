@@ -36,6 +36,10 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime; load it FIRST so this process has exactly
+    # one libamdhip64 (loading /opt/rocm's copy before torch's leaves two runtimes in the
+    # process and hipSetDevice then fails).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the MI355X ViSNet calculator needs its HIP extension "
@@ -57,6 +61,8 @@ def lib() -> C.CDLL:
     L.vsn_set_option.restype = C.c_int
     L.vsn_forces.argtypes = [vp, vp, f32p, i64p, i64p, C.c_int64, C.c_int64, f32p, f32p, vp]
     L.vsn_forces.restype = C.c_int
+    L.vsn_profile_read.argtypes = [vp, C.POINTER(C.c_double)]
+    L.vsn_profile_read.restype = C.c_int
     L.vsn_last_num_edges.argtypes = [vp]
     L.vsn_last_num_edges.restype = C.c_int64
     L.vsn_debug_read.argtypes = [vp, C.c_char_p, C.c_int, vp, C.c_int64]
@@ -71,6 +77,12 @@ def lib() -> C.CDLL:
     L.vsn_combine_plan_destroy.restype = None
     L.vsn_combine.argtypes = [vp, f32p, f32p, vp]
     L.vsn_combine.restype = C.c_int
+    L.vsn_fragplan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int64, i64p, i64p, i64p, C.POINTER(C.c_float)]
+    L.vsn_fragplan_create.restype = C.c_int
+    L.vsn_fragplan_destroy.argtypes = [vp]
+    L.vsn_fragplan_destroy.restype = None
+    L.vsn_build_fragments.argtypes = [vp, f32p, f32p, vp]
+    L.vsn_build_fragments.restype = C.c_int
     L.vsn_partition.argtypes = [i64p, i64p, C.c_int64, C.c_int, C.c_int64, i64p, C.c_int]
     L.vsn_partition.restype = C.c_int
     _lib = L
@@ -84,6 +96,7 @@ def i64_ptr(a):
 
 EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
-    "vsn_forces", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
-    "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition",
+    "vsn_forces", "vsn_profile_read", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
+    "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
+    "vsn_build_fragments",
 ]

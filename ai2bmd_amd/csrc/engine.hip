@@ -75,6 +75,8 @@ struct vsn_ctx {
   Arena ws;
   int capN = 0, capE = 0, capB = 0;
   bool debug = false;
+  bool profile = false;
+  double prof[3][4] = {{0}};  // per GEMM tile variant: launches, ms, flops, algorithmic bytes
   int64_t max_chunk_edges = 262144;
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
@@ -170,6 +172,9 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->max_chunk_edges = value;
   } else if (k == "debug") {
     c->debug = value != 0;
+  } else if (k == "profile") {
+    c->profile = value != 0;
+    memset(c->prof, 0, sizeof(c->prof));
   } else {
     return fail(c, -22, "unknown option " + k);
   }
@@ -759,11 +764,37 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       fs[(size_t)(b - b0)] = (int)(host_start[b] - a0);
       fe[(size_t)(b - b0)] = (int)(host_end[b] - a0);
     }
+    GemmProfiler gp;
+    if (c->profile) set_gemm_profiler(&gp);
     int rc = run_chunk(c, st, dev_z + a0, dev_pos + 3 * a0, fs, fe, (int)(a1 - a0), (int)(b1 - b0), (int)eb,
                        (int)maxfrag, dev_e_out + b0, dev_f_out + 3 * a0);
+    set_gemm_profiler(nullptr);
+    if (c->profile) {
+      hipStreamSynchronize(st);
+      int E = 0;
+      hipMemcpy(&E, c->ecount, sizeof(int), hipMemcpyDeviceToHost);
+      for (auto& r : gp.recs) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+        double rows = r.dev_m ? std::min(r.M, E) : r.M;
+        c->prof[r.variant][0] += 1;
+        c->prof[r.variant][1] += ms;
+        c->prof[r.variant][2] += rows * r.flops_per_row;
+        c->prof[r.variant][3] += rows * r.bytes_per_row;
+      }
+    }
     if (rc) return rc;
     b0 = b1;
   }
+  return 0;
+}
+
+extern "C" int vsn_profile_read(vsn_handle c, double* out12) {
+  if (!c || !out12) return -22;
+  for (int v = 0; v < 3; ++v)
+    for (int k = 0; k < 4; ++k) out12[v * 4 + k] = c->prof[v][k];
   return 0;
 }
 
@@ -926,6 +957,63 @@ extern "C" int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float*
   if (!p) return -22;
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   launch_combine((hipStream_t)stream, p->n_prot, p->off, p->rows, p->sign, dev_f_frag, dev_f_prot);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// ---------------------------------------------------------------------------------
+// per-step fragment geometry plan (Fragmentation/distancefrag.py:35-54)
+// ---------------------------------------------------------------------------------
+struct vsn_fragplan {
+  int device = 0;
+  int n = 0;
+  int *src = nullptr, *acc = nullptr, *tow = nullptr;
+  float* len = nullptr;
+};
+
+extern "C" int vsn_fragplan_create(vsn_fragplan_handle* out, int device_id, int64_t n, const int64_t* src,
+                                   const int64_t* acc, const int64_t* tow, const float* len) {
+  if (!out || n < 0 || !src || !acc || !tow || !len) return -22;
+  std::vector<int> s((size_t)n), a((size_t)n), t((size_t)n);
+  for (int64_t k = 0; k < n; ++k) {
+    s[(size_t)k] = (int)src[k];
+    a[(size_t)k] = (int)std::max<int64_t>(acc[k], 0);
+    t[(size_t)k] = (int)std::max<int64_t>(tow[k], 0);
+    if (src[k] < 0 && (acc[k] < 0 || tow[k] < 0 || acc[k] == tow[k])) return -22;
+  }
+  if (hipSetDevice(device_id) != hipSuccess) return -19;
+  vsn_fragplan* p = new vsn_fragplan();
+  p->device = device_id;
+  p->n = (int)n;
+  size_t nb = std::max<size_t>((size_t)n, 1);
+  if (hipMalloc((void**)&p->src, nb * 4) != hipSuccess || hipMalloc((void**)&p->acc, nb * 4) != hipSuccess ||
+      hipMalloc((void**)&p->tow, nb * 4) != hipSuccess || hipMalloc((void**)&p->len, nb * 4) != hipSuccess) {
+    delete p;
+    return -12;
+  }
+  if (n) {
+    hipMemcpy(p->src, s.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(p->acc, a.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(p->tow, t.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+    hipMemcpy(p->len, len, (size_t)n * 4, hipMemcpyHostToDevice);
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" void vsn_fragplan_destroy(vsn_fragplan_handle p) {
+  if (!p) return;
+  hipSetDevice(p->device);
+  hipFree(p->src);
+  hipFree(p->acc);
+  hipFree(p->tow);
+  hipFree(p->len);
+  delete p;
+}
+
+extern "C" int vsn_build_fragments(vsn_fragplan_handle p, const float* prot, float* out, void* stream) {
+  if (!p) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  launch_build_fragments((hipStream_t)stream, p->n, p->src, p->acc, p->tow, p->len, prot, out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

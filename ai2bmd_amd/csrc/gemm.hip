@@ -148,10 +148,40 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     }
 }
 
+// ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+static thread_local GemmProfiler* tl_prof = nullptr;
+void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
+
+int gemm_variant(int M, int Nc) {
+  if ((Nc % 128) == 0 && M >= 2048) return 0;
+  if ((Nc % 64) == 0) return 1;
+  return 2;
+}
+
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags) {
   if (M <= 0) return 0;
   if ((K & 31) || (Nc & 31) || (lda & 3) || (ldb & 3)) return -22;
+  GemmProfiler::Rec* rec = nullptr;
+  if (tl_prof) {
+    tl_prof->recs.emplace_back();
+    rec = &tl_prof->recs.back();
+    rec->variant = gemm_variant(M, Nc);
+    rec->M = M;
+    rec->dev_m = Mptr != nullptr;
+    rec->flops_per_row = 2.0 * (double)Nc * (double)K;
+    rec->bytes_per_row = 4.0 * ((double)K + (double)Nc * ((flags & 1) ? 2.0 : 1.0));
+    hipEventCreate(&rec->a);
+    hipEventCreate(&rec->b);
+    hipEventRecord(rec->a, st);
+  }
+  struct Fin {
+    GemmProfiler::Rec* r;
+    hipStream_t s;
+    ~Fin() {
+      if (r) hipEventRecord(r->b, s);
+    }
+  } fin{rec, st};
   if ((Nc % 128) == 0 && M >= 2048) {
     int grid = ((M + 127) / 128) * (Nc / 128);
     hipLaunchKernelGGL((k_gemm<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,

@@ -184,4 +184,37 @@ int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, 
   return 0;
 }
 
+// ---- per-step fragment geometry (distancefrag.py:35-54): gather + cap hydrogens ---------
+__global__ void k_build_fragments(int n, const int* __restrict__ src, const int* __restrict__ acc,
+                                  const int* __restrict__ tow, const float* __restrict__ len,
+                                  const float* __restrict__ prot, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int s = src[k];
+  float x, y, z;
+  if (s >= 0) {
+    x = prot[3 * (size_t)s + 0];
+    y = prot[3 * (size_t)s + 1];
+    z = prot[3 * (size_t)s + 2];
+  } else {
+    const int a = acc[k], t = tow[k];
+    const float ax = prot[3 * (size_t)a + 0], ay = prot[3 * (size_t)a + 1], az = prot[3 * (size_t)a + 2];
+    float dx = prot[3 * (size_t)t + 0] - ax, dy = prot[3 * (size_t)t + 1] - ay, dz = prot[3 * (size_t)t + 2] - az;
+    const float sc = len[k] / sqrtf(dx * dx + dy * dy + dz * dz);
+    x = ax + dx * sc;
+    y = ay + dy * sc;
+    z = az + dz * sc;
+  }
+  out[3 * (size_t)k + 0] = x;
+  out[3 * (size_t)k + 1] = y;
+  out[3 * (size_t)k + 2] = z;
+}
+
+int launch_build_fragments(hipStream_t st, int n, const int* src, const int* acc, const int* tow, const float* len,
+                           const float* prot, float* out) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_build_fragments, dim3(nblk(n)), dim3(256), 0, st, n, src, acc, tow, len, prot, out);
+  return 0;
+}
+
 }  // namespace vsn

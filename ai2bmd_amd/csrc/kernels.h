@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace vsn {
 
 struct GraphArgs {
@@ -43,6 +45,17 @@ struct Dims {
   const float* geo;
   const float* d;
 };
+
+struct GemmProfiler {
+  struct Rec {
+    hipEvent_t a, b;
+    int variant, M;
+    bool dev_m;
+    double flops_per_row, bytes_per_row;
+  };
+  std::vector<Rec> recs;
+};
+void set_gemm_profiler(GemmProfiler* p);  // thread-local; nullptr disables
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
@@ -107,5 +120,8 @@ int launch_fill(hipStream_t st, float* p, size_t n, float v);
 // ---- combine (Calculators/combiner.py:24-41) ----
 int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
                    const float* f_frag, float* f_prot);
+
+int launch_build_fragments(hipStream_t st, int n, const int* src, const int* acc, const int* tow, const float* len,
+                           const float* prot, float* out);
 
 }  // namespace vsn

@@ -99,6 +99,14 @@ class ViSNetEngine:
                                 C.c_void_p(f_out.data_ptr()), C.c_void_p(st.cuda_stream))
         self._check(rc)
 
+    def profile_read(self):
+        """-> {variant: dict(launches, ms, flops, bytes)} accumulated since set_option('profile', 1)."""
+        out = (C.c_double * 12)()
+        self._check(self._L.vsn_profile_read(self._h, out))
+        names = ("gemm128x128", "gemm64x64", "gemm128x32")
+        return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], flops=out[4 * v + 2], bytes=out[4 * v + 3])
+                for v in range(3)}
+
     def last_num_edges(self) -> int:
         return int(self._L.vsn_last_num_edges(self._h))
 

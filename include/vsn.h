@@ -67,8 +67,8 @@ int vsn_load_weight(vsn_handle h, const char* name, const void* ptr, const int64
  * required tensor is missing. */
 int vsn_finalize(vsn_handle h);
 
-/* Options: "max_chunk_edges" (workspace bound, default 262144),
- * "use_graph" (1 = replay a captured hipGraph when shapes repeat). */
+/* Options: "max_chunk_edges" (workspace bound, default 262144), "debug" (1 = keep per-layer
+ * snapshots for vsn_debug_read), "profile" (1 = time every GEMM launch, see vsn_profile_read). */
 int vsn_set_option(vsn_handle h, const char* key, int64_t value);
 
 /*
@@ -84,6 +84,12 @@ int vsn_set_option(vsn_handle h, const char* key, int64_t value);
  */
 int vsn_forces(vsn_handle h, const int64_t* dev_z, const float* dev_pos, const int64_t* host_start,
                const int64_t* host_end, int64_t N, int64_t B, float* dev_e_out, float* dev_f_out, void* stream);
+
+/* With option "profile"=1 every GEMM launch is bracketed by HIP events on the launch stream;
+ * this returns, per GEMM tile variant v in {0: 128x128, 1: 64x64, 2: 128x32},
+ * out[4v..4v+3] = {launches, total ms, total algorithmic flops, total algorithmic bytes}
+ * accumulated since the option was set. */
+int vsn_profile_read(vsn_handle h, double* out12);
 
 /* Device-side edge count of the last chunk processed (synchronises). */
 int64_t vsn_last_num_edges(vsn_handle h);
@@ -110,6 +116,16 @@ void vsn_combine_plan_destroy(vsn_combine_handle p);
 /* dev_f_frag f32 [n_cat,3] (interleaved order) -> dev_f_prot f32 [n_prot,3];
  * dev_e_frag f32 [B] with host-provided sign per fragment folded into plan. */
 int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float* dev_f_prot, void* stream);
+
+/* ---- per-step fragment geometry (Fragmentation/distancefrag.py:35-54 + fragments_index gather) ----
+ * Row k of the fragment batch is either a copy of protein atom host_src[k] (>= 0) or, when
+ * host_src[k] < 0, a cap hydrogen placed at  acceptor + len * unit(toward - acceptor). */
+typedef struct vsn_fragplan* vsn_fragplan_handle;
+int vsn_fragplan_create(vsn_fragplan_handle* out, int device_id, int64_t n_frag_atoms, const int64_t* host_src,
+                        const int64_t* host_acceptor, const int64_t* host_toward, const float* host_len);
+void vsn_fragplan_destroy(vsn_fragplan_handle p);
+/* dev_prot_pos f32 [n_prot,3] -> dev_frag_pos f32 [n_frag_atoms,3] */
+int vsn_build_fragments(vsn_fragplan_handle p, const float* dev_prot_pos, float* dev_frag_pos, void* stream);
 
 /* ---- work partitions (Calculators/device_strategy.py:84-127) ---- */
 /* Writes up to max_out triples (device_idx, frag_begin, frag_end); returns count. */

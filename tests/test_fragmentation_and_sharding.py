@@ -1,0 +1,112 @@
+"""CPU: fragmentation plan, combine bookkeeping, and the N>1 sharded path over a
+world_size-2 gloo group (stub force function: no GPU needed)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+def load_protein(name):
+    from ai2bmd_amd.fragmentation import ProteinAtoms
+
+    d = np.load(os.path.join(GOLDEN, f"protein_{name}.npz"))
+    return ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+
+
+@pytest.mark.parametrize("name,B,N", [("chig", 19, 391), ("trpcage", 39, 737), ("ww", 69, 1387), ("abd", 93, 1850)])
+def test_plan_sizes_match_survey(name, B, N):
+    from ai2bmd_amd.fragmentation import build_plan, fragment_positions
+
+    prot = load_protein(name)
+    plan = build_plan(prot)
+    assert len(plan.start) == B and len(plan.z) == N
+    sizes = plan.end - plan.start
+    assert (sizes[1::2] == 12).all() and sizes[0::2].min() >= 19 and sizes[0::2].max() <= 36
+    assert plan.is_dipeptide[0::2].all() and not plan.is_dipeptide[1::2].any()
+    pos = fragment_positions(plan, prot.positions)
+    cap = plan.src < 0
+    d = np.linalg.norm(pos[cap] - prot.positions[plan.acceptor[cap]], axis=1)
+    np.testing.assert_allclose(d, plan.length[cap], atol=1e-6)
+    assert set(np.round(plan.length[cap].astype(np.float64), 2).tolist()) <= {1.07, 1.02}
+    # every protein atom is covered: dipeptide copies minus ACE-NME copies == 1
+    cover = np.zeros(plan.n_prot)
+    sign = np.where(np.arange(len(plan.row_of_cat)) < plan.n_dip_rows, 1.0, -1.0)
+    np.add.at(cover, plan.origin_index, sign[plan.select_index])
+    assert (cover == 1).all()
+
+
+def test_combine_is_linear_and_matches_reference_convention():
+    from ai2bmd_amd.fragmentation import build_plan, combine_host
+
+    prot = load_protein("chig")
+    plan = build_plan(prot)
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((len(plan.z), 3))
+    e = rng.standard_normal(len(plan.start))
+    E, F = combine_host(plan, e, f)
+    # reference convention: cat[F_dip, -F_ace][select] scattered to origin
+    vd = np.zeros(len(plan.z), bool)
+    for b in range(0, len(plan.start), 2):
+        vd[plan.start[b]:plan.end[b]] = True
+    cat = np.concatenate([f[vd], -f[~vd]])[plan.select_index]
+    F2 = np.zeros_like(F)
+    np.add.at(F2, plan.origin_index, cat)
+    np.testing.assert_allclose(F, F2, atol=1e-12)
+    assert abs(E - (e[0::2].sum() - e[1::2].sum())) < 1e-12
+    # a uniform force field on every fragment copy telescopes to the same field on the protein
+    _, Fc = combine_host(plan, e, np.ones((len(plan.z), 3)))
+    np.testing.assert_allclose(Fc, 1.0)
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from ai2bmd_amd.bonded import ShardedFragmentForces
+from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, fragment_positions, combine_host
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_ww.npz"))
+prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+plan = build_plan(prot)
+ff = ShardedFragmentForces(plan, rank, world, "cpu")
+lo, hi = ff.atom_lo[rank], ff.atom_hi[rank]
+def stub_force(pos):  # deterministic per-row function standing in for vsn_forces
+    return np.stack([np.sin(pos[:, 0]) + pos[:, 1], pos[:, 2] ** 2, pos[:, 0] * pos[:, 1]], 1)
+def local_fn(prot_pos):
+    full = fragment_positions(plan, prot_pos.numpy().astype(np.float64))
+    f = stub_force(full[lo:hi])
+    e = np.array([full[s:e_].sum() for s, e_ in zip(plan.start[ff.f0:ff.f1], plan.end[ff.f0:ff.f1])])
+    return torch.as_tensor(e, dtype=torch.float32), torch.as_tensor(f, dtype=torch.float32)
+offs = ff.gathered_force_rows()
+def combine_fn(buf):
+    f_all = buf.numpy()[(offs[:, None] + np.arange(3)[None, :])]
+    return torch.as_tensor(combine_host(plan, np.zeros(len(plan.start)), f_all)[1])
+ff.local_fn, ff.combine_fn = local_fn, combine_fn
+x = torch.as_tensor(prot.positions, dtype=torch.float32)
+E, F = ff.step(x)
+full = fragment_positions(plan, prot.positions.astype(np.float32).astype(np.float64))
+e_ref = np.array([full[s:e_].sum() for s, e_ in zip(plan.start, plan.end)])
+E_ref, F_ref = combine_host(plan, e_ref, stub_force(full))
+assert abs(float(E) - E_ref) < 1e-2 * max(1, abs(E_ref)), (float(E), E_ref)
+assert np.abs(F.numpy() - F_ref).max() < 1e-3, np.abs(F.numpy() - F_ref).max()
+cover = sum(ff.rows)
+assert cover == len(plan.z) and ff.ranges[0][0] == 0 and ff.ranges[-1][1] == len(plan.start)
+print(f"rank {rank} ok rows={ff.local_rows} frags={ff.f1 - ff.f0}")
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_path_world2_gloo(tmp_path, lib_built):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", str(script), ROOT]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
