@@ -69,8 +69,35 @@ __device__ __forceinline__ void strow(float* __restrict__ row, int lane, const f
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// one wave per node, grid-strided
-#define VSN_NODE_LOOP(node, N)                                        \
-  const int lane = threadIdx.x & 63;                                  \
-  const int wv__ = threadIdx.x >> 6, nwv__ = blockDim.x >> 6;         \
-  for (int node = blockIdx.x * nwv__ + wv__; node < (N); node += gridDim.x * nwv__)
+// Node loop.  WPN = waves cooperating on ONE node:
+//   WPN == 1 : one wave per node, (blockDim/64) nodes per workgroup (large batches);
+//   WPN  > 1 : the workgroup's WPN waves split the node's edge list (edge e0+sub, e0+sub+WPN, ...)
+//              and combine their partial sums through LDS in a fixed order (small batches,
+//              e.g. one protein per MD step, where N waves cannot fill 256 CUs).
+#define VSN_NODE_LOOP(node, N, WPN)                                              \
+  const int lane = threadIdx.x & 63;                                             \
+  const int wv__ = threadIdx.x >> 6;                                             \
+  const int sub = (WPN) == 1 ? 0 : wv__;                                         \
+  const int npb__ = (WPN) == 1 ? (int)(blockDim.x >> 6) : 1;                     \
+  for (int node = blockIdx.x * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
+
+// sums acc[K][V] over the WPN waves of the workgroup into wave 0 (fixed order -> deterministic)
+template <int V, int K, int WPN>
+__device__ __forceinline__ void node_reduce(float (&acc)[K][V], float* __restrict__ smem, int lane, int sub) {
+  if (WPN == 1) return;
+  __syncthreads();  // smem may still be read from the previous use
+  if (sub > 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < V; ++c) smem[(((sub - 1) * K + k) * 64 + lane) * V + c] = acc[k][c];
+  }
+  __syncthreads();
+  if (sub == 0) {
+    for (int w = 1; w < WPN; ++w)
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c = 0; c < V; ++c) acc[k][c] += smem[(((w - 1) * K + k) * 64 + lane) * V + c];
+  }
+}

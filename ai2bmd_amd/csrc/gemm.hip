@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
 
+// 128x128 tiles only when they still give >= 4 workgroups per CU; otherwise the 4x finer
+// 64x64 tiling fills the 256 CUs better (one protein per MD step: M of a few thousand rows)
 int gemm_variant(int M, int Nc) {
-  if ((Nc % 128) == 0 && M >= 2048) return 0;
+  if ((Nc % 128) == 0 && (long long)((M + 127) / 128) * (Nc / 128) >= 1024) return 0;
   if ((Nc % 64) == 0) return 1;
   return 2;
 }
@@ -182,11 +184,12 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
       if (r) hipEventRecord(r->b, s);
     }
   } fin{rec, st};
-  if ((Nc % 128) == 0 && M >= 2048) {
+  const int variant = gemm_variant(M, Nc);
+  if (variant == 0) {
     int grid = ((M + 127) / 128) * (Nc / 128);
     hipLaunchKernelGGL((k_gemm<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags);
-  } else if ((Nc % 64) == 0) {
+  } else if (variant == 1) {
     int grid = ((M + 63) / 64) * (Nc / 64);
     hipLaunchKernelGGL((k_gemm<64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags);

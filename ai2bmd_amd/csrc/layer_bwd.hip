@@ -19,38 +19,51 @@
 
 namespace vsn {
 
-#define VSN_DISPATCH_VS(H_, S_, FN, ...)                                 \
+// template dispatch on V = H/64 (1,2,4), S (3,8) and WPN (1 or VSN_WPN_SMALL)
+#define VSN_WPN_SMALL 8
+#define VSN_DISPATCH3(V_, S_, W_, FN, ...)                              \
+  do {                                                                   \
+    if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
+    else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
+  } while (0)
+#define VSN_DISPATCH_VS(H_, S_, W_, FN, ...)                             \
   do {                                                                   \
     const int v__ = (H_) / 64;                                           \
     if ((S_) == 8) {                                                     \
-      if (v__ == 4) FN<4, 8> __VA_ARGS__;                                \
-      else if (v__ == 2) FN<2, 8> __VA_ARGS__;                           \
-      else if (v__ == 1) FN<1, 8> __VA_ARGS__;                           \
+      if (v__ == 4) VSN_DISPATCH3(4, 8, W_, FN, __VA_ARGS__);            \
+      else if (v__ == 2) VSN_DISPATCH3(2, 8, W_, FN, __VA_ARGS__);       \
+      else if (v__ == 1) VSN_DISPATCH3(1, 8, W_, FN, __VA_ARGS__);       \
       else return -22;                                                   \
     } else if ((S_) == 3) {                                              \
-      if (v__ == 4) FN<4, 3> __VA_ARGS__;                                \
-      else if (v__ == 2) FN<2, 3> __VA_ARGS__;                           \
-      else if (v__ == 1) FN<1, 3> __VA_ARGS__;                           \
+      if (v__ == 4) VSN_DISPATCH3(4, 3, W_, FN, __VA_ARGS__);            \
+      else if (v__ == 2) VSN_DISPATCH3(2, 3, W_, FN, __VA_ARGS__);       \
+      else if (v__ == 1) VSN_DISPATCH3(1, 3, W_, FN, __VA_ARGS__);       \
       else return -22;                                                   \
     } else return -22;                                                   \
   } while (0)
 
-static inline int node_grid(int N) {
-  int g = (N + 3) / 4;
+// small batches (one protein per MD step): several waves per node
+static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
+static inline int node_grid(int N, int wpn) {
+  int g = wpn == 1 ? (N + 3) / 4 : N;
   if (g > 16384) g = 16384;
   if (g < 1) g = 1;
   return g;
 }
+static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
+// LDS for node_reduce of K*V*64 floats per extra wave
+static inline size_t node_lds(int wpn, int K, int V) { return wpn == 1 ? 0 : (size_t)(wpn - 1) * K * V * 64 * 4; }
 
 // ---- adjoint of the node update (visnet_block.py:271-274) ------------------------
 // g_o = [sum_s g_vec*vec3 | g_x*vec_dot | g_x] ; g_vp = [g_vdot*vec2 | g_vdot*vec1 | g_vec*o1]
-template <int V, int S>
+template <int V, int S, int WPN>
 __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __restrict__ g_x,
                                                          const float* __restrict__ g_vec,
                                                          const float* __restrict__ vp, const float* __restrict__ o,
                                                          float* __restrict__ g_o, float* __restrict__ g_vp) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, 1) {
+    (void)sub;
     float gx[V], o1[V], o2[V], gvd[V], vd[V], go1[V];
     ldrow<V>(g_x + (size_t)i * H, lane, gx);
     ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
@@ -95,13 +108,13 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // wd = u1.u2 + a1 a2 cc ; df = silu(pf) wd
 // g_pf = g_f wd silu'(pf) ; g_wd = g_f silu(pf)
 // g_wt_i = sum_e g_wd (u2 + a2 cc d) ; g_d += sum_c g_wd (cc (a2 u1 + a1 u2) + 2 a1 a2 d)
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_edge_update_T(Dims D, const float* __restrict__ vp,
-                                                           const float* __restrict__ pe,
-                                                           const float* __restrict__ g_f, float* __restrict__ g_pe,
-                                                           float* __restrict__ g_vp, float* __restrict__ g_geo) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
+    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
+    float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float wt[S][V], gwt[S][V];
 #pragma unroll
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(256) void k_bwd_edge_update_T(Dims D, const float* 
 #pragma unroll
       for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
     }
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float u2[S][V], dd[S];
       float dot[V], a1[V], a2[V];
@@ -155,26 +168,29 @@ __global__ __launch_bounds__(256) void k_bwd_edge_update_T(Dims D, const float* 
       }
       if (lane < S) g_geo[(size_t)e * 16 + lane] += mine;
     }
+    node_reduce<V, S, WPN>(gwt, smem, lane, sub);
+    if (sub == 0) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, gwt[s]);
+      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, gwt[s]);
+    }
   }
 }
 
 // ---- adjoint of the edge update, source side: g_ws_j = sum_{e: src=j} g_wd (u1 + a1 cc d) ----
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_edge_update_S(Dims D, const float* __restrict__ vp,
-                                                           const float* __restrict__ pe,
-                                                           const float* __restrict__ g_f,
-                                                           float* __restrict__ g_vp) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
+    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
+    float* __restrict__ g_vp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(j, D.N) {
+  VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
     float gws[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) gws[s][c] = 0.f;
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0 + sub; t < t1; t += WPN) {
       const int e = uni(D.perm[t]);
       const int i = uni(D.tgt[e]);
       float u1[S][V], dd[S], a1[V];
@@ -199,25 +215,28 @@ __global__ __launch_bounds__(256) void k_bwd_edge_update_S(Dims D, const float* 
 #pragma unroll
         for (int c = 0; c < V; ++c) gws[s][c] += gwd[c] * (u1[s][c] + a1[c] * cc * dd[s]);
     }
+    node_reduce<V, S, WPN>(gws, smem, lane, sub);
+    if (sub == 0) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
+      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
+    }
   }
 }
 
 // ---- adjoint of the vector messages, target side -----------------------------------
 // mv_e[s] = vh_j[s] s1 + d_s s2 ; g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_s
 // g_t = [g_s1 silu'(t1) | g_s2 silu'(t2)] ; g_d[s] += sum_c g_vec_i[s] s2
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_vecmsg_T(Dims D, const float* __restrict__ g_vec,
-                                                      const float* __restrict__ vh, const float* __restrict__ tpre,
-                                                      float* __restrict__ g_t, float* __restrict__ g_geo) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
+    Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
+    float* __restrict__ g_t, float* __restrict__ g_geo) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float gv[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float t1[V], t2[V], s2[V], d1[V], d2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, t1);
@@ -259,18 +278,19 @@ __global__ __launch_bounds__(256) void k_bwd_vecmsg_T(Dims D, const float* __res
 }
 
 // ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_vecmsg_S(Dims D, const float* __restrict__ g_vec,
-                                                      const float* __restrict__ tpre, float* __restrict__ g_vh) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
+    Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(j, D.N) {
+  VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
     float acc[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) acc[s][c] = 0.f;
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0 + sub; t < t1; t += WPN) {
       const int e = uni(D.perm[t]);
       const int i = uni(D.tgt[e]);
       float s1[V];
@@ -285,8 +305,11 @@ __global__ __launch_bounds__(256) void k_bwd_vecmsg_S(Dims D, const float* __res
         for (int c = 0; c < V; ++c) acc[s][c] += gv[c] * s1[c];
       }
     }
+    node_reduce<V, S, WPN>(acc, smem, lane, sub);
+    if (sub == 0) {
 #pragma unroll
-    for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
+      for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
+    }
   }
 }
 
@@ -294,23 +317,23 @@ __global__ __launch_bounds__(256) void k_bwd_vecmsg_S(Dims D, const float* __res
 // gm = g_m_e + g_A_i (overwrites g_m) ; recompute sat, a
 // g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a silu'(sat) C ; g_C += sum_h g_a silu(sat)
 // g_pk = g_sat q_i k_j silu'(pk) ; g_pv = gm v_j a silu'(pv) ; g_q_i = sum_e g_sat k_j dk
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_attn_T(Dims D, const float* __restrict__ qkv,
-                                                    const float* __restrict__ pe, const float* __restrict__ g_A,
-                                                    float* __restrict__ g_m, float* __restrict__ g_pe,
-                                                    float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
-                                                    float* __restrict__ g_geo) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
+    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
+    float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
+    float* __restrict__ g_geo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   const int nh = D.nh;
   const int lph = 64 / nh;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    float q[V], gA[V], gq[V];
+    float q[V], gA[V], gq[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
     ldrow<V>(g_A + (size_t)i * H, lane, gA);
 #pragma unroll
-    for (int c = 0; c < V; ++c) gq[c] = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    for (int c = 0; c < V; ++c) gq[0][c] = 0.f;
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       const float C = D.geo[(size_t)e * 8 + 1];
       float k[V], v[V], pk[V], pv[V], gm[V];
@@ -348,29 +371,31 @@ __global__ __launch_bounds__(256) void k_bwd_attn_T(Dims D, const float* __restr
       for (int c = 0; c < V; ++c) {
         gpk[c] = gsat * q[c] * k[c] * ddk[c];
         gpv[c] = gm[c] * v[c] * a * ddv[c];
-        gq[c] += gsat * k[c] * dk[c];
+        gq[0][c] += gsat * k[c] * dk[c];
       }
       strow<V>(g_pe + (size_t)e * 3 * H, lane, gpk);
       strow<V>(g_pe + (size_t)e * 3 * H + H, lane, gpv);
     }
-    strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq);
+    node_reduce<V, 1, WPN>(gq, smem, lane, sub);
+    if (sub == 0) strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq[0]);
   }
 }
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_attn_S(Dims D, const float* __restrict__ qkv,
-                                                    const float* __restrict__ pe, const float* __restrict__ g_m,
-                                                    const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
+    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_m,
+    const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   const int nh = D.nh;
   const int lph = 64 / nh;
-  VSN_NODE_LOOP(j, D.N) {
+  VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
-    float gk[V], gv[V];
+    float g2[2][V];
 #pragma unroll
-    for (int c = 0; c < V; ++c) gk[c] = gv[c] = 0.f;
-    for (int t = t0; t < t1; ++t) {
+    for (int c = 0; c < V; ++c) g2[0][c] = g2[1][c] = 0.f;
+    for (int t = t0 + sub; t < t1; t += WPN) {
       const int e = uni(D.perm[t]);
       const int i = uni(D.tgt[e]);
       float q[V], pk[V], pv[V], gm[V];
@@ -382,17 +407,20 @@ __global__ __launch_bounds__(256) void k_bwd_attn_S(Dims D, const float* __restr
       const float a = sat_tmp[(size_t)e * 2 * nh + nh + lane / lph];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        gk[c] += gsat * q[c] * silu_f(pk[c]);
-        gv[c] += gm[c] * silu_f(pv[c]) * a;
+        g2[0][c] += gsat * q[c] * silu_f(pk[c]);
+        g2[1][c] += gm[c] * silu_f(pv[c]) * a;
       }
     }
-    strow<V>(g_qkv + (size_t)j * 3 * H + H, lane, gk);
-    strow<V>(g_qkv + (size_t)j * 3 * H + 2 * H, lane, gv);
+    node_reduce<V, 2, WPN>(g2, smem, lane, sub);
+    if (sub == 0) {
+      strow<V>(g_qkv + (size_t)j * 3 * H + H, lane, g2[0]);
+      strow<V>(g_qkv + (size_t)j * 3 * H + 2 * H, lane, g2[1]);
+    }
   }
 }
 
 // ---- adjoint of LayerNorm + VecLayerNorm("none") ------------------------------------
-template <int V, int S>
+template <int V, int S, int WPN>
 __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __restrict__ g_xh, int ldg,
                                                        const float* __restrict__ g_vh,
                                                        const float* __restrict__ xn, const float* __restrict__ rstd,
@@ -401,7 +429,8 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
                                                        float* __restrict__ g_x, float* __restrict__ g_vec) {
   const int H = D.H;
   const float invH = 1.0f / (float)H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, 1) {
+    (void)sub;
     float g[V], n[V], ga[V], w[V];
     ldrow<V>(g_xh + (size_t)i * ldg, lane, g);
     ldrow<V>(xn + (size_t)i * H, lane, n);
@@ -445,18 +474,20 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
 
 // ---- adjoint of EdgeEmbedding (utils.py:331-337) -----------------------------------
 // g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_embed_edge(Dims D, const float* __restrict__ x,
-                                                        const float* __restrict__ pp, const float* __restrict__ g_f,
-                                                        float* __restrict__ g_pp, float* __restrict__ g_x) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
+    Dims D, const float* __restrict__ x, const float* __restrict__ pp, const float* __restrict__ g_f,
+    float* __restrict__ g_pp, float* __restrict__ g_x) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int t0 = uni(D.colptr[i]), t1 = uni(D.colptr[i + 1]);
-    float xi[V], acc[V];
+    float xi[V], acc[1][V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
-    ldrow<V>(g_x + (size_t)i * H, lane, acc);
-    for (int e = e0; e < e1; ++e) {
+#pragma unroll
+    for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float xj[V], ps[V], gf[V], gp[V];
       ldrow<V>(x + (size_t)j * H, lane, xj);
@@ -465,34 +496,41 @@ __global__ __launch_bounds__(256) void k_bwd_embed_edge(Dims D, const float* __r
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gp[c] = gf[c] * (xi[c] + xj[c]);
-        acc[c] += gf[c] * ps[c];
+        acc[0][c] += gf[c] * ps[c];
       }
       strow<V>(g_pp + (size_t)e * 2 * H + H, lane, gp);
     }
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0 + sub; t < t1; t += WPN) {
       const int e = uni(D.perm[t]);
       float ps[V], gf[V];
       ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
       ldrow<V>(g_f + (size_t)e * H, lane, gf);
 #pragma unroll
-      for (int c = 0; c < V; ++c) acc[c] += gf[c] * ps[c];
+      for (int c = 0; c < V; ++c) acc[0][c] += gf[c] * ps[c];
     }
-    strow<V>(g_x + (size_t)i * H, lane, acc);
+    node_reduce<V, 1, WPN>(acc, smem, lane, sub);
+    if (sub == 0) {
+      float gx[V];
+      ldrow<V>(g_x + (size_t)i * H, lane, gx);
+#pragma unroll
+      for (int c = 0; c < V; ++c) gx[c] += acc[0][c];
+      strow<V>(g_x + (size_t)i * H, lane, gx);
+    }
   }
 }
 
 // ---- adjoint of NeighborEmbedding's aggregation (utils.py:296-317) -------------------
 // g_Wn = g_n_i emb2[z_j] (non-loop) ; g_phi = g_Wn C ; g_C += sum_c g_Wn phi
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_bwd_embed_node(Dims D, const float* __restrict__ emb2,
-                                                        const float* __restrict__ pp, const float* __restrict__ g_n,
-                                                        float* __restrict__ g_pp, float* __restrict__ g_geo) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
+    Dims D, const float* __restrict__ emb2, const float* __restrict__ pp, const float* __restrict__ g_n,
+    float* __restrict__ g_pp, float* __restrict__ g_geo) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float gn[V];
     ldrow<V>(g_n + (size_t)i * H, lane, gn);
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float gph[V];
       if (j == i) {
@@ -520,33 +558,39 @@ __global__ __launch_bounds__(256) void k_bwd_embed_node(Dims D, const float* __r
 }
 
 // ---- launchers -----------------------------------------------------------------------
+#define VSN_LAUNCH(KN, RK, ...)                                                                         \
+  do {                                                                                                  \
+    const int w__ = pick_wpn(D.N);                                                                      \
+    VSN_DISPATCH_VS(D.H, D.S, w__, KN,                                                                  \
+                    <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
+  } while (0)
+
 int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, const float* g_vec, const float* vp,
                            const float* o, float* g_o, float* g_vp) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_node_update, <<<node_grid(D.N), 256, 0, st>>>(D, g_x, g_vec, vp, o, g_o, g_vp));
+  VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_node_update,
+                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_x, g_vec, vp, o, g_o, g_vp));
   return 0;
 }
 int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
                            float* g_pe, float* g_vp, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_edge_update_T,
-                  <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo));
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_edge_update_S, <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, g_f, g_vp));
+  VSN_LAUNCH(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
+  VSN_LAUNCH(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
   return 0;
 }
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
                       float* g_t, float* g_vh, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_vecmsg_T, <<<node_grid(D.N), 256, 0, st>>>(D, g_vec, vh, tpre, g_t, g_geo));
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_vecmsg_S, <<<node_grid(D.N), 256, 0, st>>>(D, g_vec, tpre, g_vh));
+  VSN_LAUNCH(k_bwd_vecmsg_T, 0, D, g_vec, vh, tpre, g_t, g_geo);
+  VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
   return 0;
 }
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_attn_T,
-                  <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo));
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_attn_S, <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, g_m, sat_tmp, g_qkv));
+  VSN_LAUNCH(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo);
+  VSN_LAUNCH(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
   return 0;
 }
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh,
@@ -554,21 +598,21 @@ int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int l
                          int accumulate, float* g_x, float* g_vec) {
   if (D.N <= 0) return 0;
   if (norm_type != 0) return -38;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_node_norm,
-                  <<<node_grid(D.N), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
-                                                   g_vec));
+  VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_node_norm,
+                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
+                                                      g_vec));
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
                           float* g_pp, float* g_x) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_embed_edge, <<<node_grid(D.N), 256, 0, st>>>(D, x, pp, g_f, g_pp, g_x));
+  VSN_LAUNCH(k_bwd_embed_edge, 1, D, x, pp, g_f, g_pp, g_x);
   return 0;
 }
 int launch_bwd_embed_node(hipStream_t st, const Dims& D, const float* emb2, const float* pp, const float* g_n,
                           float* g_pp, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_bwd_embed_node, <<<node_grid(D.N), 256, 0, st>>>(D, emb2, pp, g_n, g_pp, g_geo));
+  VSN_LAUNCH(k_bwd_embed_node, 0, D, emb2, pp, g_n, g_pp, g_geo);
   return 0;
 }
 

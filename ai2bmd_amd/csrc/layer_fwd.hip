@@ -17,42 +17,56 @@
 
 namespace vsn {
 
-#define VSN_DISPATCH_VS(H_, S_, FN, ...)                                 \
+// template dispatch on V = H/64 (1,2,4), S (3,8) and WPN (1 or VSN_WPN_SMALL)
+#define VSN_WPN_SMALL 8
+#define VSN_DISPATCH3(V_, S_, W_, FN, ...)                              \
+  do {                                                                   \
+    if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
+    else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
+  } while (0)
+#define VSN_DISPATCH_VS(H_, S_, W_, FN, ...)                             \
   do {                                                                   \
     const int v__ = (H_) / 64;                                           \
     if ((S_) == 8) {                                                     \
-      if (v__ == 4) FN<4, 8> __VA_ARGS__;                                \
-      else if (v__ == 2) FN<2, 8> __VA_ARGS__;                           \
-      else if (v__ == 1) FN<1, 8> __VA_ARGS__;                           \
+      if (v__ == 4) VSN_DISPATCH3(4, 8, W_, FN, __VA_ARGS__);            \
+      else if (v__ == 2) VSN_DISPATCH3(2, 8, W_, FN, __VA_ARGS__);       \
+      else if (v__ == 1) VSN_DISPATCH3(1, 8, W_, FN, __VA_ARGS__);       \
       else return -22;                                                   \
     } else if ((S_) == 3) {                                              \
-      if (v__ == 4) FN<4, 3> __VA_ARGS__;                                \
-      else if (v__ == 2) FN<2, 3> __VA_ARGS__;                           \
-      else if (v__ == 1) FN<1, 3> __VA_ARGS__;                           \
+      if (v__ == 4) VSN_DISPATCH3(4, 3, W_, FN, __VA_ARGS__);            \
+      else if (v__ == 2) VSN_DISPATCH3(2, 3, W_, FN, __VA_ARGS__);       \
+      else if (v__ == 1) VSN_DISPATCH3(1, 3, W_, FN, __VA_ARGS__);       \
       else return -22;                                                   \
     } else return -22;                                                   \
   } while (0)
 
-static inline int node_grid(int N) {
-  int g = (N + 3) / 4;
+// small batches (one protein per MD step): several waves per node
+static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
+static inline int node_grid(int N, int wpn) {
+  int g = wpn == 1 ? (N + 3) / 4 : N;
   if (g > 16384) g = 16384;
   if (g < 1) g = 1;
   return g;
 }
+static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
+// LDS for node_reduce of K*V*64 floats per extra wave
+static inline size_t node_lds(int wpn, int K, int V) { return wpn == 1 ? 0 : (size_t)(wpn - 1) * K * V * 64 * 4; }
 
 // ---- embeddings -------------------------------------------------------------
 // cat[i] = [ emb1[z_i] | sum_{j->i, j!=i} emb2[z_j] * phi_e * C_e ]   (utils.py:296-317)
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_embed_node(Dims D, const float* __restrict__ emb1,
-                                                    const float* __restrict__ emb2, const float* __restrict__ pp,
-                                                    float* __restrict__ cat) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_node(Dims D, const float* __restrict__ emb1,
+                                                                          const float* __restrict__ emb2,
+                                                                          const float* __restrict__ pp,
+                                                                          float* __restrict__ cat) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    float acc[V];
+    float acc[1][V];
 #pragma unroll
-    for (int c = 0; c < V; ++c) acc[c] = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       if (j == i) continue;
       const float C = D.geo[(size_t)e * 8 + 1];
@@ -60,26 +74,30 @@ __global__ __launch_bounds__(256) void k_embed_node(Dims D, const float* __restr
       ldrow<V>(emb2 + (size_t)uni(D.zi[j]) * H, lane, em);
       ldrow<V>(pp + (size_t)e * 2 * H, lane, ph);
 #pragma unroll
-      for (int c = 0; c < V; ++c) acc[c] += em[c] * (ph[c] * C);
+      for (int c = 0; c < V; ++c) acc[0][c] += em[c] * (ph[c] * C);
     }
-    float x0[V];
-    ldrow<V>(emb1 + (size_t)uni(D.zi[i]) * H, lane, x0);
-    strow<V>(cat + (size_t)i * 2 * H, lane, x0);
-    strow<V>(cat + (size_t)i * 2 * H + H, lane, acc);
+    node_reduce<V, 1, WPN>(acc, smem, lane, sub);
+    if (sub == 0) {
+      float x0[V];
+      ldrow<V>(emb1 + (size_t)uni(D.zi[i]) * H, lane, x0);
+      strow<V>(cat + (size_t)i * 2 * H, lane, x0);
+      strow<V>(cat + (size_t)i * 2 * H + H, lane, acc[0]);
+    }
   }
 }
 
 // f_e = (x_i + x_j) * psi_e for all edges incl. loops (utils.py:331-337); vec = 0
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_embed_edge(Dims D, const float* __restrict__ x,
-                                                    const float* __restrict__ pp, float* __restrict__ f,
-                                                    float* __restrict__ vec) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D, const float* __restrict__ x,
+                                                                          const float* __restrict__ pp,
+                                                                          float* __restrict__ f,
+                                                                          float* __restrict__ vec) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float xi[V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float xj[V], ps[V], o[V];
       ldrow<V>(x + (size_t)j * H, lane, xj);
@@ -91,13 +109,12 @@ __global__ __launch_bounds__(256) void k_embed_edge(Dims D, const float* __restr
     float zr[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) zr[c] = 0.f;
-#pragma unroll
-    for (int s = 0; s < S; ++s) strow<V>(vec + ((size_t)i * S + s) * H, lane, zr);
+    for (int s = sub; s < S; s += WPN) strow<V>(vec + ((size_t)i * S + s) * H, lane, zr);
   }
 }
 
 // ---- LayerNorm + VecLayerNorm (visnet_block.py:238-239, utils.py:186-249) -----
-template <int V, int S>
+template <int V, int S, int WPN>
 __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restrict__ x, const float* __restrict__ vec,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                    const float* __restrict__ wvec, int norm_type,
@@ -105,7 +122,8 @@ __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restri
                                                    float* __restrict__ xh, int ldxh, float* __restrict__ vh) {
   const int H = D.H;
   const float invH = 1.0f / (float)H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, 1) {
+    (void)sub;
     float xv[V], g[V], b[V], w[V];
     ldrow<V>(x + (size_t)i * H, lane, xv);
     ldrow<V>(gamma, lane, g);
@@ -146,19 +164,21 @@ __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restri
 
 // ---- attention + scalar message + its aggregation (visnet_block.py:276-283,305) --
 // a_h = silu(sum_c q_i k_j dk) * C ; m_e = v_j * dv * a ; A_i = sum_e m_e
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_edge_attn(Dims D, const float* __restrict__ qkv,
-                                                   const float* __restrict__ pe, float* __restrict__ m,
-                                                   float* __restrict__ A) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D, const float* __restrict__ qkv,
+                                                                         const float* __restrict__ pe,
+                                                                         float* __restrict__ m,
+                                                                         float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   const int lph = 64 / D.nh;  // lanes per head
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    float q[V], acc[V];
+    float q[V], acc[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
 #pragma unroll
-    for (int c = 0; c < V; ++c) acc[c] = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       const float C = D.geo[(size_t)e * 8 + 1];
       float k[V], v[V], pk[V], pv[V], mv[V];
@@ -174,31 +194,35 @@ __global__ __launch_bounds__(256) void k_edge_attn(Dims D, const float* __restri
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         mv[c] = v[c] * silu_f(pv[c]) * a;
-        acc[c] += mv[c];
+        acc[0][c] += mv[c];
       }
       strow<V>(m + (size_t)e * H, lane, mv);
     }
-    strow<V>(A + (size_t)i * H, lane, acc);
+    node_reduce<V, 1, WPN>(acc, smem, lane, sub);
+    if (sub == 0) strow<V>(A + (size_t)i * H, lane, acc[0]);
   }
 }
 
 // ---- vector messages, their aggregation and the node update ---------------------
 // V_i[s] = sum_e vh_j[s]*s1_e + d_e[s]*s2_e ; dx = (sum_s vec1 vec2) o2 + o3 ;
 // dvec = vec3 o1 + V ; x += dx ; vec += dvec    (visnet_block.py:284-288,271-274,129-137)
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_node_update(Dims D, const float* __restrict__ tpre,
-                                                     const float* __restrict__ vh, const float* __restrict__ vp,
-                                                     const float* __restrict__ o, float* __restrict__ x,
-                                                     float* __restrict__ vec) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims D, const float* __restrict__ tpre,
+                                                                           const float* __restrict__ vh,
+                                                                           const float* __restrict__ vp,
+                                                                           const float* __restrict__ o,
+                                                                           float* __restrict__ x,
+                                                                           float* __restrict__ vec) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float Va[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) Va[s][c] = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float s1[V], s2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
@@ -217,47 +241,51 @@ __global__ __launch_bounds__(256) void k_node_update(Dims D, const float* __rest
         for (int c = 0; c < V; ++c) Va[s][c] += vj[c] * s1[c] + ds * s2[c];
       }
     }
-    float o1[V], o2[V], o3[V], vd[V];
-    ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
-    ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
-    ldrow<V>(o + (size_t)i * 3 * H + 2 * H, lane, o3);
+    node_reduce<V, S, WPN>(Va, smem, lane, sub);
+    if (sub == 0) {
+      float o1[V], o2[V], o3[V], vd[V];
+      ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+      ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+      ldrow<V>(o + (size_t)i * 3 * H + 2 * H, lane, o3);
 #pragma unroll
-    for (int c = 0; c < V; ++c) vd[c] = 0.f;
+      for (int c = 0; c < V; ++c) vd[c] = 0.f;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      const float* row = vp + ((size_t)i * S + s) * 5 * H;
-      float v1[V], v2[V], v3[V], vv[V];
-      ldrow<V>(row, lane, v1);
-      ldrow<V>(row + H, lane, v2);
-      ldrow<V>(row + 2 * H, lane, v3);
-      ldrow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
+      for (int s = 0; s < S; ++s) {
+        const float* row = vp + ((size_t)i * S + s) * 5 * H;
+        float v1[V], v2[V], v3[V], vv[V];
+        ldrow<V>(row, lane, v1);
+        ldrow<V>(row + H, lane, v2);
+        ldrow<V>(row + 2 * H, lane, v3);
+        ldrow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
 #pragma unroll
-      for (int c = 0; c < V; ++c) {
-        vd[c] += v1[c] * v2[c];
-        vv[c] += v3[c] * o1[c] + Va[s][c];
+        for (int c = 0; c < V; ++c) {
+          vd[c] += v1[c] * v2[c];
+          vv[c] += v3[c] * o1[c] + Va[s][c];
+        }
+        strow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
       }
-      strow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
-    }
-    float xv[V];
-    ldrow<V>(x + (size_t)i * H, lane, xv);
+      float xv[V];
+      ldrow<V>(x + (size_t)i * H, lane, xv);
 #pragma unroll
-    for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
-    strow<V>(x + (size_t)i * H, lane, xv);
+      for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
+      strow<V>(x + (size_t)i * H, lane, xv);
+    }
   }
 }
 
 // ---- edge update (visnet_block.py:290-295): f_e += silu(pf_e) * <rej(wt_i,d), rej(ws_j,d)> ---
 // <w1,w2> = u1.u2 + (u1.d)(u2.d)(|d|^2 - 2)   (expanded double rejection)
-template <int V, int S>
-__global__ __launch_bounds__(256) void k_edge_update(Dims D, const float* __restrict__ vp,
-                                                     const float* __restrict__ pe, float* __restrict__ f) {
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims D, const float* __restrict__ vp,
+                                                                           const float* __restrict__ pe,
+                                                                           float* __restrict__ f) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N) {
+  VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float wt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, wt[s]);
-    for (int e = e0; e < e1; ++e) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float dot[V], a1[V], a2[V];
 #pragma unroll
@@ -287,15 +315,22 @@ __global__ __launch_bounds__(256) void k_edge_update(Dims D, const float* __rest
 }
 
 // ---- launchers -------------------------------------------------------------------
+#define VSN_LAUNCH(KN, RK, ...)                                                                         \
+  do {                                                                                                  \
+    const int w__ = pick_wpn(D.N);                                                                      \
+    VSN_DISPATCH_VS(D.H, D.S, w__, KN,                                                                  \
+                    <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
+  } while (0)
+
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
                       float* cat) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_embed_node, <<<node_grid(D.N), 256, 0, st>>>(D, emb1, emb2, pp, cat));
+  VSN_LAUNCH(k_embed_node, 1, D, emb1, emb2, pp, cat);
   return 0;
 }
 int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_embed_edge, <<<node_grid(D.N), 256, 0, st>>>(D, x, pp, f, vec));
+  VSN_LAUNCH(k_embed_edge, 0, D, x, pp, f, vec);
   return 0;
 }
 int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
@@ -303,24 +338,25 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
                      int ldxh, float* vh) {
   if (D.N <= 0) return 0;
   if (norm_type != 0) return -38;
-  VSN_DISPATCH_VS(D.H, D.S, k_node_norm,
-                  <<<node_grid(D.N), 256, 0, st>>>(D, x, vec, gamma, beta, wvec, norm_type, xn, rstd, xh, ldxh, vh));
+  VSN_DISPATCH_VS(D.H, D.S, 1, k_node_norm,
+                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, x, vec, gamma, beta, wvec, norm_type, xn, rstd, xh, ldxh,
+                                                      vh));
   return 0;
 }
 int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_edge_attn, <<<node_grid(D.N), 256, 0, st>>>(D, qkv, pe, m, A));
+  VSN_LAUNCH(k_edge_attn, 1, D, qkv, pe, m, A);
   return 0;
 }
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
                        const float* o, float* x, float* vec) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_node_update, <<<node_grid(D.N), 256, 0, st>>>(D, tpre, vh, vp, o, x, vec));
+  VSN_LAUNCH(k_node_update, D.S, D, tpre, vh, vp, o, x, vec);
   return 0;
 }
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, k_edge_update, <<<node_grid(D.N), 256, 0, st>>>(D, vp, pe, f));
+  VSN_LAUNCH(k_edge_update, 0, D, vp, pe, f);
   return 0;
 }
 
