@@ -90,6 +90,8 @@ struct vsn_ctx {
   float *g_x, *g_vec, *g_f;
   float *g_o, *g_vp, *g_A, *g_t, *g_m, *g_pe, *g_qkv, *g_vh, *g_xh, *sat_tmp;
   float *g_pp, *g_n, *g_rbf, *g_geo, *g_ev;
+  float* splitk;
+  size_t splitk_elems = 0;
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -527,6 +529,9 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
   c->g_rbf = a.take<float>(e * Rp);
   c->g_geo = a.take<float>(e * 16);
   c->g_ev = a.take<float>(e * 4);
+  // split-K partials: up to 8 slices of the widest narrow output ([E,H] or [S*N,H])
+  c->splitk_elems = 8 * std::max(e, n * S) * H;
+  c->splitk = a.take<float>(c->splitk_elems);
 }
 
 static int ensure_ws(vsn_ctx* c, int N, int E, int Bn) {
@@ -766,9 +771,13 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
     }
     GemmProfiler gp;
     if (c->profile) set_gemm_profiler(&gp);
+    int rc0 = ensure_ws(c, (int)(a1 - a0), (int)eb, (int)(b1 - b0));
+    if (rc0) return rc0;
+    set_gemm_splitk_workspace(c->splitk, c->splitk_elems);
     int rc = run_chunk(c, st, dev_z + a0, dev_pos + 3 * a0, fs, fe, (int)(a1 - a0), (int)(b1 - b0), (int)eb,
                        (int)maxfrag, dev_e_out + b0, dev_f_out + 3 * a0);
     set_gemm_profiler(nullptr);
+    set_gemm_splitk_workspace(nullptr, 0);
     if (c->profile) {
       hipStreamSynchronize(st);
       int E = 0;
@@ -890,7 +899,24 @@ extern "C" int vsn_gemm(vsn_handle c, const float* A, int lda, const float* Bt, 
                         const float* bias, int M, int Nc, int K, int flags, void* stream) {
   if (!c) return -22;
   HIPCHK(c, hipSetDevice(c->device));
+  // test/bench tap: a persistent scratch buffer so the split-K path is exercised too
+  static thread_local float* scratch = nullptr;
+  static thread_local size_t scratch_elems = 0;
+  const size_t elems = (size_t)8 * (size_t)std::max(M, 1) * (size_t)Nc;
+  if (K >= 512 && (size_t)M * Nc <= ((size_t)1 << 26)) {
+    if (elems > scratch_elems) {
+      if (scratch) {
+        hipDeviceSynchronize();
+        hipFree(scratch);
+      }
+      scratch_elems = 0;
+      if (hipMalloc((void**)&scratch, elems * sizeof(float)) == hipSuccess) scratch_elems = elems;
+      else scratch = nullptr;
+    }
+    if (scratch) set_gemm_splitk_workspace(scratch, scratch_elems);
+  }
   int rc = launch_gemm((hipStream_t)stream, A, lda, Bt, ldb, C, ldc, bias, M, nullptr, Nc, K, flags);
+  set_gemm_splitk_workspace(nullptr, 0);
   if (rc) return fail(c, rc, "gemm: unsupported shape (K, Nc multiples of 32; lda/ldb multiples of 4)");
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(c, -5, hipGetErrorString(le));

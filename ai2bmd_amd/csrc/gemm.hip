@@ -25,15 +25,15 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, int M,
-                                              const int* __restrict__ Mptr, int Nc, int K, int flags) {
+                                              const int* __restrict__ Mptr, int Nc, int K, int flags,
+                                              int ksplit, float* __restrict__ part) {
   constexpr int BK = 32;
   constexpr int LS = BK + 4;  // padded LDS row stride (floats)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int LA = BM / 32, LB = BN / 32;  // float4 loads per thread per k-tile
-  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
-  float* As = smem;
-  float* Bs = smem + BM * LS;
+  constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
+  constexpr int STAGE = (BM + BN) * LS;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // double buffered
 
   int Meff = M;
   if (Mptr) {
@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     Meff = md < M ? md : M;
   }
   const int tiles_n = Nc / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tile = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
   if (row0 >= Meff) return;
 
@@ -50,6 +51,11 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
   const bool silu_a = (flags & 2) != 0;
+  // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce)
+  const int nkt_all = K / BK;
+  const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
+  const int nkt = kt1 - kt0;
+  const int kbase = kt0 * BK;
 
   f32x4 ra[LA], rb[LB];
 #define VSN_GLOAD(k0)                                                                        \
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
       const int r_ = f_ >> 3, c4_ = f_ & 7;                                                  \
       int gr_ = row0 + r_;                                                                   \
       gr_ = gr_ < Meff ? gr_ : Meff - 1; /* clamp: rows >= Meff are never stored */          \
-      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4);     \
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4);      \
     }                                                                                        \
     _Pragma("unroll") for (int it = 0; it < LB; ++it) {                                      \
       const int f_ = tid + it * 256;                                                         \
@@ -67,24 +73,26 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
       rb[it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r_) * ldb + (k0) + c4_ * 4); \
     }                                                                                        \
   }
-#define VSN_SSTORE()                                                          \
+#define VSN_SSTORE(buf)                                                       \
   {                                                                           \
+    float* As_ = smem + (buf) * STAGE;                                        \
+    float* Bs_ = As_ + BM * LS;                                               \
     _Pragma("unroll") for (int it = 0; it < LA; ++it) {                       \
       const int f_ = tid + it * 256;                                          \
       const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
-      f32x4 v_ = ra[it];                                                     \
+      f32x4 v_ = ra[it];                                                      \
       if (silu_a) {                                                           \
         v_.x = silu_f(v_.x);                                                  \
         v_.y = silu_f(v_.y);                                                  \
         v_.z = silu_f(v_.z);                                                  \
         v_.w = silu_f(v_.w);                                                  \
       }                                                                       \
-      *reinterpret_cast<f32x4*>(As + r_ * LS + c4_ * 4) = v_;                \
+      *reinterpret_cast<f32x4*>(As_ + r_ * LS + c4_ * 4) = v_;                \
     }                                                                         \
     _Pragma("unroll") for (int it = 0; it < LB; ++it) {                       \
       const int f_ = tid + it * 256;                                          \
       const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
-      *reinterpret_cast<f32x4*>(Bs + r_ * LS + c4_ * 4) = rb[it];            \
+      *reinterpret_cast<f32x4*>(Bs_ + r_ * LS + c4_ * 4) = rb[it];            \
     }                                                                         \
   }
 
@@ -96,16 +104,17 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nkt = K / BK;
-  VSN_GLOAD(0);
+  // software pipeline: LDS holds tile kt (buffer kt&1), registers hold tile kt+1, one barrier per tile
+  VSN_GLOAD(kbase);
+  VSN_SSTORE(0);
+  {
+    const int kn = (1 < nkt ? 1 : 0) * BK + kbase;
+    VSN_GLOAD(kn);
+  }
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    VSN_SSTORE();
-    __syncthreads();
-    {
-      // always prefetch (the last iteration re-reads its own tile; harmless, keeps ra/rb in registers)
-      const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK;
-      VSN_GLOAD(kn);
-    }
+    const float* As = smem + (kt & 1) * STAGE;
+    const float* Bs = As + BM * LS;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[MI], b[NI];
@@ -125,6 +134,12 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (kt + 1 < nkt) {
+      // tile kt+1 (in registers) -> the other LDS buffer (last read in iteration kt-1, a barrier ago)
+      VSN_SSTORE((kt + 1) & 1);
+      const int kn = (kt + 2 < nkt ? kt + 2 : kt + 1) * BK + kbase;
+      VSN_GLOAD(kn);
+    }
     __syncthreads();
   }
 
@@ -134,23 +149,59 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = col0 + wn * TN + j * 32 + l31;
-      const float bv = bias ? bias[col] : 0.f;
+      const float bv = (bias && ksplit == 1) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (row < Meff) {
-          float* cp = C + (size_t)row * ldc + col;
-          float v = acc[i][j][r] + bv;
-          if (accum) v += *cp;
-          *cp = v;
+          if (ksplit == 1) {
+            float* cp = C + (size_t)row * ldc + col;
+            float v = acc[i][j][r] + bv;
+            if (accum) v += *cp;
+            *cp = v;
+          } else {
+            part[((size_t)ks * M + row) * Nc + col] = acc[i][j][r];
+          }
         }
       }
     }
+#undef VSN_GLOAD
+#undef VSN_SSTORE
+}
+
+// split-K epilogue: C (+)= sum_s part[s] (+ bias), fixed summation order
+__global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float* __restrict__ C, int ldc,
+                              const float* __restrict__ bias, int M, const int* __restrict__ Mptr, int Nc,
+                              int flags) {
+  int Meff = M;
+  if (Mptr) {
+    int md = *Mptr;
+    Meff = md < M ? md : M;
+  }
+  const int nc4 = Nc >> 2;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long row = gid / nc4;
+  const int c4 = (int)(gid % nc4);
+  if (row >= Meff) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(part + ((size_t)row) * Nc + c4 * 4);
+  for (int k = 1; k < ksplit; ++k)
+    s += *reinterpret_cast<const f32x4*>(part + ((size_t)k * M + row) * Nc + c4 * 4);
+  if (bias) s += *reinterpret_cast<const f32x4*>(bias + c4 * 4);
+  float* cp = C + (size_t)row * ldc + c4 * 4;
+  if (flags & 1) s += *reinterpret_cast<const f32x4*>(cp);
+  *reinterpret_cast<f32x4*>(cp) = s;
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
+// split-K scratch (set by the engine per chunk; nullptr disables split-K)
+static thread_local float* tl_splitk_ws = nullptr;
+static thread_local size_t tl_splitk_elems = 0;
+void set_gemm_splitk_workspace(float* p, size_t elems) {
+  tl_splitk_ws = p;
+  tl_splitk_elems = elems;
+}
 
 // 128x128 tiles only when they still give >= 4 workgroups per CU; otherwise the 4x finer
 // 64x64 tiling fills the 256 CUs better (one protein per MD step: M of a few thousand rows)
@@ -185,18 +236,35 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
     }
   } fin{rec, st};
   const int variant = gemm_variant(M, Nc);
+  const int bm = variant == 1 ? 64 : 128, bn = variant == 0 ? 128 : (variant == 1 ? 64 : 32);
+  const int tiles = ((M + bm - 1) / bm) * (Nc / bn);
+  // split-K: few output tiles and a long K (the dX = dY.W products of the reverse pass on small
+  // batches) would leave most CUs idle; cut K over `ks` workgroups and reduce deterministically.
+  int ks = 1;
+  if (tiles < 768 && K >= 512 && tl_splitk_ws && (ldc & 3) == 0) {
+    ks = (1024 + tiles - 1) / tiles;
+    const int kmax = K / 128;  // keep >= 4 k-tiles per split
+    if (ks > kmax) ks = kmax;
+    if (ks > 8) ks = 8;
+    while (ks > 1 && (size_t)ks * M * Nc > tl_splitk_elems) --ks;
+    if (ks < 1) ks = 1;
+  }
+  float* part = ks > 1 ? tl_splitk_ws : nullptr;
+  const int grid = tiles * ks;
   if (variant == 0) {
-    int grid = ((M + 127) / 128) * (Nc / 128);
     hipLaunchKernelGGL((k_gemm<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
-                       Mptr, Nc, K, flags);
+                       Mptr, Nc, K, flags, ks, part);
   } else if (variant == 1) {
-    int grid = ((M + 63) / 64) * (Nc / 64);
     hipLaunchKernelGGL((k_gemm<64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
-                       Mptr, Nc, K, flags);
+                       Mptr, Nc, K, flags, ks, part);
   } else {
-    int grid = ((M + 127) / 128) * (Nc / 32);
     hipLaunchKernelGGL((k_gemm<128, 32, 4, 1>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
-                       Mptr, Nc, K, flags);
+                       Mptr, Nc, K, flags, ks, part);
+  }
+  if (ks > 1) {
+    long long n4 = (long long)M * (Nc / 4);
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, ks, C, ldc, bias,
+                       M, Mptr, Nc, flags);
   }
   return 0;
 }

@@ -56,6 +56,7 @@ struct GemmProfiler {
   std::vector<Rec> recs;
 };
 void set_gemm_profiler(GemmProfiler* p);  // thread-local; nullptr disables
+void set_gemm_splitk_workspace(float* p, size_t elems);  // thread-local scratch for split-K partials
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);

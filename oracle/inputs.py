@@ -38,12 +38,16 @@ def random_fragments(seed, sizes, cutoff=5.0, margin=2e-3):
         s += n
         if n == 0:
             continue
-        while True:
+        # big clusters have ~n^2/2 pairs: keep the exclusion band small enough to be satisfiable
+        band = margin if n <= 64 else margin * (64.0 / n) ** 2
+        for attempt in range(200):
             p = random_cluster(rng, n).astype(np.float32)
             p += rng.uniform(-20, 20, size=3).astype(np.float32)
             d = np.linalg.norm(p[:, None, :].astype(np.float64) - p[None, :, :], axis=-1)
-            if np.abs(d - cutoff).min() > margin:
+            if np.abs(d - cutoff).min() > band:
                 break
+        else:
+            raise RuntimeError("could not place a cluster away from the cutoff")
         ps.append(p)
         zs.append(rng.choice(ELEMENTS, size=n))
     z = np.concatenate(zs).astype(np.int64) if zs else np.zeros(0, np.int64)

@@ -17,7 +17,8 @@ def eng(lib_built):
 
 
 @pytest.mark.parametrize("M,Nc,K", [(1, 32, 32), (37, 64, 96), (300, 96, 64), (1000, 256, 256), (4099, 768, 256),
-                                    (2500, 256, 768), (5000, 1280, 256), (129, 32, 512), (6000, 128, 32)])
+                                    (2500, 256, 768), (5000, 1280, 256), (129, 32, 512), (6000, 128, 32),
+                                    (391, 256, 768), (3128, 256, 1280), (6651, 256, 512), (70000, 256, 768)])
 @pytest.mark.parametrize("flags", [0, 1, 2])
 def test_gemm_matches_fp64(eng, M, Nc, K, flags):
     g = torch.Generator().manual_seed(M * 7 + Nc + K + flags)

@@ -177,3 +177,37 @@ def test_checkpoint_file_roundtrip(lib_built, tmp_path):
     calc = ViSNetCalculator(model)
     calc.calculate(Atoms(), ["energy", "forces"], None)
     check(calc.results["energy"], calc.results["forces"], g["E_ref64"], g["F_ref64"])
+
+
+@pytest.mark.parametrize("sizes", [[1], [2, 1, 0, 0, 3], [0, 0, 12, 0], [300], [64, 65, 1, 130]])
+def test_edge_case_batches(lib_built, sizes):
+    """Single atoms (self loop only), empty fragments at either end, fragments larger than a
+    wavefront / with neighbour truncation (whole-molecule mode)."""
+    hp = default_hparams(embedding_dimension=64, num_layers=2, max_num_neighbors=32)
+    sd = make_state_dict(hp, seed=5)
+    z, pos, start, end = random_fragments(sum(sizes) + 7, sizes)
+    E64, F64, c = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    assert m.engine.last_num_edges() == len(c["graph"]["src"])
+    check(e, f, E64, F64)
+
+
+def test_isolated_atoms_and_cutoff(lib_built):
+    """Two atoms beyond the cutoff do not interact: forces vanish and E = 2 single-atom energies."""
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    sd = make_state_dict(hp, seed=6)
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    z = np.array([6, 6, 6], dtype=np.int64)
+    pos = np.array([[0, 0, 0], [7.5, 0, 0], [100, 0, 0]], dtype=np.float32)
+    e2, f2 = m.dl_potential_loader(frag(z, pos, np.array([0, 2]), np.array([2, 3])))
+    assert np.abs(f2).max() == 0.0
+    assert abs((e2[0, 0] - hp_mean(sd)) - 2 * (e2[1, 0] - hp_mean(sd))) < 1e-5
+
+
+def hp_mean(sd):
+    return float(sd["mean"])
