@@ -41,6 +41,7 @@ struct LayerW {
 
 struct LayerBuf {
   float *xn, *rstd, *vh, *qkv, *vp, *pe, *tpre, *o;
+  float* vin;  // pre-norm vec, saved only for vecnorm rms / max_min
 };
 
 struct Arena {
@@ -84,7 +85,7 @@ struct vsn_ctx {
   float *pp, *cat, *x_emb, *x, *vec, *f;
   std::vector<LayerBuf> lb;
   float *xh, *m, *A;
-  float *xn_o, *rstd_o, *vo;
+  float *xn_o, *rstd_o, *vo, *vin_o;
   HeadBuf hb;
   float* g_vo;
   float *g_x, *g_vec, *g_f;
@@ -131,8 +132,7 @@ extern "C" int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id)
     return fail(c, -22, "num_heads must be a power of two <= 64 dividing hidden");
   if ((c->H / c->nh) % (c->H / 64)) return fail(c, -22, "head_dim must be a multiple of hidden/64");
   if (c->L < 1) return fail(c, -22, "num_layers must be >= 1");
-  if (hp->vecnorm_type != VSN_VECNORM_NONE)
-    return fail(c, -38, "vecnorm_type rms/max_min not built yet in the HIP path");
+  if (hp->vecnorm_type < 0 || hp->vecnorm_type > 2) return fail(c, -22, "unknown vecnorm_type");
   if (hipSetDevice(device_id) != hipSuccess) return fail(c, -19, "hipSetDevice failed (no MI355X visible?)");
   return 0;
 }
@@ -485,6 +485,7 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
     b.pe = a.take<float>(e * 3 * H);
     b.tpre = a.take<float>(e * 2 * H);
     b.o = a.take<float>(n * 3 * H);
+    b.vin = c->hp.vecnorm_type ? a.take<float>(n * S * H) : nullptr;
   }
   c->xh = a.take<float>(n * H);
   c->m = a.take<float>(e * H);
@@ -492,6 +493,7 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
   c->xn_o = a.take<float>(n * H);
   c->rstd_o = a.take<float>(n);
   c->vo = a.take<float>(n * S * H);
+  c->vin_o = c->hp.vecnorm_type ? a.take<float>(n * S * H) : nullptr;
   HeadBuf& hb = c->hb;
   hb.cat0 = a.take<float>(n * 2 * H);
   hb.pv0 = a.take<float>(n * S * (H + h2));
@@ -668,6 +670,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "f_in", l, c->f, (size_t)Emax * H);
     RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
                         b.vh));
+    if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
     RC(launch_gemm(st, c->xh, H, w.Wqkv, H, b.qkv, 3 * H, w.bqkv, N, nullptr, 3 * H, H, 0));
     RC(launch_gemm(st, b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0));
     RC(launch_gemm(st, c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, last ? 2 * H : 3 * H, H, 0));
@@ -684,11 +687,14 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   // ---- read-out ----
   RC(launch_node_norm(st, D, c->x, c->vec, c->on_g, c->on_b, c->vo_w, c->hp.vecnorm_type, c->xn_o, c->rstd_o,
                       c->hb.cat0, 2 * H, c->vo));
+  if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, c->vo_w, c->vin_o, c->vo));
   RC(launch_head_forward(st, D, c->hw, c->hb, c->vo, c->fstart, c->fend, Bn, e_out));
   // ---- reverse pass ----
   RC(launch_head_backward(st, D, c->hw, c->hb, c->g_vo));
   RC(launch_bwd_node_norm(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w,
                           c->hp.vecnorm_type, 0, c->g_x, c->g_vec));
+  if (c->hp.vecnorm_type)
+    RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, c->vin_o, c->vo_w, c->g_vo, 0, c->g_vec));
   snapshot(c, st, "g_x_in", L, c->g_x, (size_t)N * H);
   snapshot(c, st, "g_vec_in", L, c->g_vec, (size_t)N * S * H);
   for (int l = L - 1; l >= 0; --l) {
@@ -715,6 +721,9 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
     RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, c->hp.vecnorm_type, 1,
                             c->g_x, c->g_vec));
+    // layer 0 normalises vec == 0, which does not depend on the positions: nothing to propagate
+    if (c->hp.vecnorm_type && l > 0)
+      RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, b.vin, w.vln_w, c->g_vh, 1, c->g_vec));
     snapshot(c, st, "g_x_in", l, c->g_x, (size_t)N * H);
     snapshot(c, st, "g_vec_in", l, c->g_vec, (size_t)N * S * H);
     snapshot(c, st, "g_f_in", l, c->g_f, (size_t)Emax * H);

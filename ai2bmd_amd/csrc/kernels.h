@@ -117,6 +117,11 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
 int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, float* g_vo);
 
 int launch_fill(hipStream_t st, float* p, size_t n, float v);
+// VecLayerNorm rms (1) / max_min (2): vh = norm(vec), also saves vec into vin for the adjoint
+int launch_vecnorm_fwd(hipStream_t st, int N, int H, int S, int norm_type, const float* vec, const float* w,
+                       float* vin, float* vh);
+int launch_vecnorm_bwd(hipStream_t st, int N, int H, int S, int norm_type, const float* vin, const float* w,
+                       const float* g_vh, int accumulate, float* g_vec);
 
 // ---- combine (Calculators/combiner.py:24-41) ----
 int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,

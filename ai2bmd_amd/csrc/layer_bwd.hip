@@ -425,8 +425,9 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
                                                        const float* __restrict__ g_vh,
                                                        const float* __restrict__ xn, const float* __restrict__ rstd,
                                                        const float* __restrict__ gamma,
-                                                       const float* __restrict__ wvec, int accumulate,
-                                                       float* __restrict__ g_x, float* __restrict__ g_vec) {
+                                                       const float* __restrict__ wvec, int norm_type,
+                                                       int accumulate, float* __restrict__ g_x,
+                                                       float* __restrict__ g_vec) {
   const int H = D.H;
   const float invH = 1.0f / (float)H;
   VSN_NODE_LOOP(i, D.N, 1) {
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
 #pragma unroll
     for (int c = 0; c < V; ++c) out[c] += rs * (g[c] - m1 - n[c] * m2);
     strow<V>(g_x + (size_t)i * H, lane, out);
+    if (norm_type == 0)  // "none": g_vec (+)= g_vh * w ; rms / max_min adjoints live in vecnorm.hip
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       float gv[V], o[V];
@@ -597,10 +599,9 @@ int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int l
                          const float* xn, const float* rstd, const float* gamma, const float* wvec, int norm_type,
                          int accumulate, float* g_x, float* g_vec) {
   if (D.N <= 0) return 0;
-  if (norm_type != 0) return -38;
   VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_node_norm,
-                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
-                                                      g_vec));
+                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, norm_type,
+                                                      accumulate, g_x, g_vec));
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,

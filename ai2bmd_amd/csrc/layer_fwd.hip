@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restri
     strow<V>(xn + (size_t)i * H, lane, n);
     strow<V>(xh + (size_t)i * ldxh, lane, h);
     if (lane == 0) rstd[i] = rs;
-    // VecLayerNorm, norm_type 0 ("none"): vh = vec * weight
+    // VecLayerNorm, norm_type 0 ("none"): vh = vec * weight  (rms / max_min: vecnorm.hip)
+    if (norm_type == 0)
 #pragma unroll
     for (int sidx = 0; sidx < S; ++sidx) {
       float v[V];
@@ -337,7 +338,6 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
                      const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
                      int ldxh, float* vh) {
   if (D.N <= 0) return 0;
-  if (norm_type != 0) return -38;
   VSN_DISPATCH_VS(D.H, D.S, 1, k_node_norm,
                   <<<node_grid(D.N, 1), 256, 0, st>>>(D, x, vec, gamma, beta, wvec, norm_type, xn, rstd, xh, ldxh,
                                                       vh));

@@ -26,8 +26,7 @@ def load_golden(name):
 
 GOLDEN_CASES = ["h64_l2", "h128_l3_lmax1", "h64_l2_trunc", "h256_l9_default", "h64_l3_rms", "h64_l3_maxmin",
                 "h64_l2_whole"]
-# cases the HIP path supports today (vecnorm_type == "none")
-HIP_CASES = ["h64_l2", "h128_l3_lmax1", "h64_l2_trunc", "h256_l9_default", "h64_l2_whole"]
+HIP_CASES = list(GOLDEN_CASES)
 
 
 @pytest.fixture(scope="session")

@@ -211,3 +211,17 @@ def test_isolated_atoms_and_cutoff(lib_built):
 
 def hp_mean(sd):
     return float(sd["mean"])
+
+
+@pytest.mark.parametrize("vn,lmax,H", [("rms", 2, 128), ("max_min", 2, 128), ("rms", 1, 64), ("max_min", 1, 256)])
+def test_vecnorm_variants_fresh_seed(lib_built, vn, lmax, H):
+    """VecLayerNorm rms / max_min (utils.py:186-249) and their hand-derived adjoints."""
+    hp = default_hparams(embedding_dimension=H, num_layers=3, vecnorm_type=vn, lmax=lmax)
+    sd = make_state_dict(hp, seed=31)
+    z, pos, start, end = random_fragments(77, [22, 12, 0, 31])
+    E64, F64, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    check(e, f, E64, F64)
