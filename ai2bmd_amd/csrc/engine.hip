@@ -562,6 +562,9 @@ static int ensure_ws(vsn_ctx* c, int N, int E, int Bn) {
   c->capN = nN;
   c->capE = nE;
   c->capB = nB;
+  // layer 0 sees vec == 0 (visnet_block.py:119-121): its vector projections are identically zero and are
+  // never computed; the buffer is cleared once per allocation.
+  HIPCHK(c, hipMemset(c->lb[0].vp, 0, (size_t)nN * c->S * 5 * c->H * sizeof(float)));
   return 0;
 }
 
@@ -672,15 +675,17 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
                         b.vh));
     if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
     RC(launch_gemm(st, c->xh, H, w.Wqkv, H, b.qkv, 3 * H, w.bqkv, N, nullptr, 3 * H, H, 0));
-    RC(launch_gemm(st, b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0));
-    RC(launch_gemm(st, c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, last ? 2 * H : 3 * H, H, 0));
+    // layer 0: vec == 0 -> vec1..3, w_trg.v, w_src.v are 0 (buffer pre-cleared) and df == 0 (no f_proj needed)
+    const bool l0 = (l == 0);
+    if (!l0) RC(launch_gemm(st, b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0));
+    RC(launch_gemm(st, c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, (last || l0) ? 2 * H : 3 * H, H, 0));
     RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
     snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
     snapshot(c, st, "A", l, c->A, (size_t)N * H);
     RC(launch_gemm(st, c->m, H, w.Ws, H, b.tpre, 2 * H, w.bs, Emax, EP, 2 * H, H, 0));
     RC(launch_gemm(st, c->A, H, w.Wo, H, b.o, 3 * H, w.bo, N, nullptr, 3 * H, H, 0));
     RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec));
-    if (!last) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
+    if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
   }
   snapshot(c, st, "x_in", L, c->x, (size_t)N * H);
   snapshot(c, st, "vec_in", L, c->vec, (size_t)N * S * H);
@@ -703,8 +708,10 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     LayerBuf& b = c->lb[l];
     RC(launch_bwd_node_update(st, D, c->g_x, c->g_vec, b.vp, b.o, c->g_o, c->g_vp));
     RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));
-    if (!last) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
-    RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, c->g_vh, c->g_geo));
+    // layer 0: the edge update and everything flowing into vec_in (== 0, position independent) vanish
+    const bool l0 = (l == 0);
+    if (!last && !l0) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
+    RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
     RC(launch_gemm(st, c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0));
     RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo));
@@ -713,14 +720,16 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);
     snapshot(c, st, "g_vp", l, c->g_vp, (size_t)N * S * 5 * H);
     snapshot(c, st, "g_A", l, c->g_A, (size_t)N * H);
-    RC(launch_gemm(st, c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H, last ? 2 * H : 3 * H, 1));
-    RC(launch_gemm(st, c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
-                   last ? 3 * H : 5 * H, 1));
+    RC(launch_gemm(st, c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H,
+                   (last || l0) ? 2 * H : 3 * H, 1));
+    if (!l0)
+      RC(launch_gemm(st, c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
+                     last ? 3 * H : 5 * H, 1));
     RC(launch_gemm(st, c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0));
     snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
-    RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, c->hp.vecnorm_type, 1,
-                            c->g_x, c->g_vec));
+    RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
+                            l0 ? 3 /* skip the vec part */ : c->hp.vecnorm_type, 1, c->g_x, c->g_vec));
     // layer 0 normalises vec == 0, which does not depend on the positions: nothing to propagate
     if (c->hp.vecnorm_type && l > 0)
       RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, b.vin, w.vln_w, c->g_vh, 1, c->g_vec));

@@ -15,12 +15,14 @@
 // Each lane reads 4 consecutive k of its row: lanes 0-31 take k0..k0+3, lanes
 // 32-63 take k0+4..k0+7; MFMA #t pairs (k0+t, k0+4+t) for A and B alike, so
 // the k-sum is just reordered.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace vsn {
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DB>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
   constexpr int STAGE = (BM + BN) * LS;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];  // double buffered
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
 
   int Meff = M;
   if (Mptr) {
@@ -104,16 +106,26 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // software pipeline: LDS holds tile kt (buffer kt&1), registers hold tile kt+1, one barrier per tile
-  VSN_GLOAD(kbase);
-  VSN_SSTORE(0);
-  {
-    const int kn = (1 < nkt ? 1 : 0) * BK + kbase;
-    VSN_GLOAD(kn);
+  if (DB) {
+    // software pipeline: LDS holds tile kt (buffer kt&1), registers hold tile kt+1, one barrier per tile
+    VSN_GLOAD(kbase);
+    VSN_SSTORE(0);
+    {
+      const int kn = (1 < nkt ? 1 : 0) * BK + kbase;
+      VSN_GLOAD(kn);
+    }
+    __syncthreads();
+  } else {
+    VSN_GLOAD(kbase);
   }
-  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const float* As = smem + (kt & 1) * STAGE;
+    if (!DB) {
+      VSN_SSTORE(0);
+      __syncthreads();
+      const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK + kbase;
+      VSN_GLOAD(kn);
+    }
+    const float* As = smem + (DB ? (kt & 1) : 0) * STAGE;
     const float* Bs = As + BM * LS;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nkt) {
+    if (DB && kt + 1 < nkt) {
       // tile kt+1 (in registers) -> the other LDS buffer (last read in iteration kt-1, a barrier ago)
       VSN_SSTORE((kt + 1) & 1);
       const int kn = (kt + 2 < nkt ? kt + 2 : kt + 1) * BK + kbase;
@@ -193,6 +205,7 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
 // split-K scratch (set by the engine per chunk; nullptr disables split-K)
@@ -235,6 +248,12 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
       if (r) hipEventRecord(r->b, s);
     }
   } fin{rec, st};
+  static const bool env_init = [] {
+    const char* e = getenv("VSN_GEMM_DB128");
+    if (e) g_gemm_db128 = atoi(e);
+    return true;
+  }();
+  (void)env_init;
   const int variant = gemm_variant(M, Nc);
   const int bm = variant == 1 ? 64 : 128, bn = variant == 0 ? 128 : (variant == 1 ? 64 : 32);
   const int tiles = ((M + bm - 1) / bm) * (Nc / bn);
@@ -252,13 +271,15 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   float* part = ks > 1 ? tl_splitk_ws : nullptr;
   const int grid = tiles * ks;
   if (variant == 0) {
-    hipLaunchKernelGGL((k_gemm<128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+    if (g_gemm_db128) hipLaunchKernelGGL((k_gemm<128, 128, 2, 2, true>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+                       Mptr, Nc, K, flags, ks, part);
+    else hipLaunchKernelGGL((k_gemm<128, 128, 2, 2, false>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags, ks, part);
   } else if (variant == 1) {
-    hipLaunchKernelGGL((k_gemm<64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+    hipLaunchKernelGGL((k_gemm<64, 64, 2, 2, true>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags, ks, part);
   } else {
-    hipLaunchKernelGGL((k_gemm<128, 32, 4, 1>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
+    hipLaunchKernelGGL((k_gemm<128, 32, 4, 1, true>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags, ks, part);
   }
   if (ks > 1) {

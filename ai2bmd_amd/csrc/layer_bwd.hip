@@ -585,7 +585,7 @@ int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const f
                       float* g_t, float* g_vh, float* g_geo) {
   if (D.N <= 0) return 0;
   VSN_LAUNCH(k_bwd_vecmsg_T, 0, D, g_vec, vh, tpre, g_t, g_geo);
-  VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
+  if (g_vh) VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
   return 0;
 }
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,

@@ -45,9 +45,12 @@ def load_protein(name):
 
 
 def fwd_flops(N, E, H, L, S, R):
-    """Algorithmic forward FLOPs of one evaluation (minimal formulation)."""
-    return ((L - 1) * ((12 + 10 * S) * N * H * H + 10 * E * H * H) + ((12 + 6 * S) * N * H * H + 8 * E * H * H)
+    """Algorithmic forward FLOPs of one evaluation (minimal formulation), minus the
+    layer-0 vector projections (10*S*N*H^2) and f_proj (2*E*H^2): vec == 0 entering layer 0
+    (visnet_block.py:119-121) makes them identically zero, so they are never computed."""
+    full = ((L - 1) * ((12 + 10 * S) * N * H * H + 10 * E * H * H) + ((12 + 6 * S) * N * H * H + 8 * E * H * H)
             + (3.5 * S + 7) * N * H * H + 4 * N * H * H + 2 * R * H * (2 * E - N))
+    return full - (10 * S * N * H * H + 2 * E * H * H if L > 1 else 6 * S * N * H * H)
 
 
 def cpu_baseline_md(plan, prot, hp, sd, budget_s=20.0):

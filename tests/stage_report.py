@@ -101,7 +101,7 @@ def main(name):
         pe = rd("pe", l).reshape(E_, 3 * H)
         cmp(f"L{l}.pk", pe[:, :H], t(lc["pk"]))
         cmp(f"L{l}.pv", pe[:, H:2 * H], t(lc["pv"]))
-        if not last:
+        if not last and l > 0:  # layer 0: vec == 0, these are identically zero / unused and never computed
             cmp(f"L{l}.wt", vp[..., 3 * H:4 * H], t(lc["wt"]))
             cmp(f"L{l}.ws", vp[..., 4 * H:], t(lc["ws"]))
             cmp(f"L{l}.pf", pe[:, 2 * H:], t(lc["pf"]))
@@ -134,7 +134,7 @@ def main(name):
         cmp(f"L{l}.g_A", rd("g_A", l), t(lb["g_A"]))
         gvp = rd("g_vp", l).reshape(N, S, 5 * H)
         cmp(f"L{l}.g_vp", gvp[..., :3 * H], t(lb["g_vp"]))
-        if not last:
+        if not last and l > 0:
             cmp(f"L{l}.g_wt", gvp[..., 3 * H:4 * H], t(lb["g_wt"]))
             cmp(f"L{l}.g_ws", gvp[..., 4 * H:], t(lb["g_ws"]))
         cmp(f"L{l}.g_t", rd("g_t", l), t(lb["g_t"]))
@@ -142,13 +142,14 @@ def main(name):
         gpe = rd("g_pe", l).reshape(E_, 3 * H)
         cmp(f"L{l}.g_pk", gpe[:, :H], t(lb["g_pk"]))
         cmp(f"L{l}.g_pv", gpe[:, H:2 * H], t(lb["g_pv"]))
-        if not last:
+        if not last and l > 0:
             cmp(f"L{l}.g_pf", gpe[:, 2 * H:], t(lb["g_pf"]))
         cmp(f"L{l}.g_qkv", rd("g_qkv", l), np.concatenate([t(lb["g_q"]), t(lb["g_k"]), t(lb["g_v"])], 1))
-        cmp(f"L{l}.g_vh", rd("g_vh", l), t(lb["g_vh"]))
+        if l > 0:  # the adjoint of vec_in(0) == 0 is not needed
+            cmp(f"L{l}.g_vh", rd("g_vh", l), t(lb["g_vh"]))
+            cmp(f"L{l}.g_vec_in", rd("g_vec_in", l), t(lb["g_vec_in"]))
         cmp(f"L{l}.g_xh", rd("g_xh", l), t(lb["g_xh"]))
         cmp(f"L{l}.g_x_in", rd("g_x_in", l), t(lb["g_x_in"]))
-        cmp(f"L{l}.g_vec_in", rd("g_vec_in", l), t(lb["g_vec_in"]))
         cmp(f"L{l}.g_f_in", rd("g_f_in", l), t(lb["g_f_in"]))
     cmp("g_x_emb", rd("g_x"), t(b["g_x_emb"]))
     cmp("g_n", rd("g_n"), t(b["g_n"]))
