@@ -674,16 +674,25 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
                         b.vh));
     if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
-    RC(launch_gemm(st, c->xh, H, w.Wqkv, H, b.qkv, 3 * H, w.bqkv, N, nullptr, 3 * H, H, 0));
     // layer 0: vec == 0 -> vec1..3, w_trg.v, w_src.v are 0 (buffer pre-cleared) and df == 0 (no f_proj needed)
     const bool l0 = (l == 0);
-    if (!l0) RC(launch_gemm(st, b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0));
-    RC(launch_gemm(st, c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, (last || l0) ? 2 * H : 3 * H, H, 0));
+    {
+      GemmDesc gd[3];
+      int ng = 0;
+      gd[ng++] = gemm_desc(c->xh, H, w.Wqkv, H, b.qkv, 3 * H, w.bqkv, N, nullptr, 3 * H, H, 0);
+      if (!l0) gd[ng++] = gemm_desc(b.vh, H, w.Wv5, H, b.vp, 5 * H, nullptr, N * S, nullptr, last ? 3 * H : 5 * H, H, 0);
+      gd[ng++] = gemm_desc(c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, (last || l0) ? 2 * H : 3 * H, H, 0);
+      RC(launch_gemm_group(st, gd, ng));
+    }
     RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
     snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
     snapshot(c, st, "A", l, c->A, (size_t)N * H);
-    RC(launch_gemm(st, c->m, H, w.Ws, H, b.tpre, 2 * H, w.bs, Emax, EP, 2 * H, H, 0));
-    RC(launch_gemm(st, c->A, H, w.Wo, H, b.o, 3 * H, w.bo, N, nullptr, 3 * H, H, 0));
+    {
+      GemmDesc gd[2];
+      gd[0] = gemm_desc(c->m, H, w.Ws, H, b.tpre, 2 * H, w.bs, Emax, EP, 2 * H, H, 0);
+      gd[1] = gemm_desc(c->A, H, w.Wo, H, b.o, 3 * H, w.bo, N, nullptr, 3 * H, H, 0);
+      RC(launch_gemm_group(st, gd, 2));
+    }
     RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec));
     if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
   }
@@ -720,12 +729,17 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);
     snapshot(c, st, "g_vp", l, c->g_vp, (size_t)N * S * 5 * H);
     snapshot(c, st, "g_A", l, c->g_A, (size_t)N * H);
-    RC(launch_gemm(st, c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H,
-                   (last || l0) ? 2 * H : 3 * H, 1));
-    if (!l0)
-      RC(launch_gemm(st, c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
-                     last ? 3 * H : 5 * H, 1));
-    RC(launch_gemm(st, c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0));
+    {
+      GemmDesc gd[3];
+      int ng = 0;
+      gd[ng++] = gemm_desc(c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H,
+                           (last || l0) ? 2 * H : 3 * H, 1);
+      if (!l0)
+        gd[ng++] = gemm_desc(c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
+                             last ? 3 * H : 5 * H, 1);
+      gd[ng++] = gemm_desc(c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0);
+      RC(launch_gemm_group(st, gd, ng));
+    }
     snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
     RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
@@ -805,11 +819,19 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
         hipEventElapsedTime(&ms, r.a, r.b);
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
-        double rows = r.dev_m ? std::min(r.M, E) : r.M;
         c->prof[r.variant][0] += 1;
         c->prof[r.variant][1] += ms;
-        c->prof[r.variant][2] += rows * r.flops_per_row;
-        c->prof[r.variant][3] += rows * r.bytes_per_row;
+        if (r.group_n > 0) {
+          for (int g = 0; g < r.group_n; ++g) {
+            double rows = r.gdev[g] ? std::min(r.gM[g], E) : r.gM[g];
+            c->prof[r.variant][2] += rows * r.gflops[g];
+            c->prof[r.variant][3] += rows * r.gbytes[g];
+          }
+        } else {
+          double rows = r.dev_m ? std::min(r.M, E) : r.M;
+          c->prof[r.variant][2] += rows * r.flops_per_row;
+          c->prof[r.variant][3] += rows * r.bytes_per_row;
+        }
       }
     }
     if (rc) return rc;

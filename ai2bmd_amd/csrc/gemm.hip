@@ -23,19 +23,17 @@
 namespace vsn {
 
 template <int BM, int BN, int WM, int WN, bool DB>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
-                                              const float* __restrict__ Bt, int ldb,
-                                              float* __restrict__ C, int ldc,
-                                              const float* __restrict__ bias, int M,
-                                              const int* __restrict__ Mptr, int Nc, int K, int flags,
-                                              int ksplit, float* __restrict__ part) {
+__device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
+                                          int ldb, float* __restrict__ C, int ldc,
+                                          const float* __restrict__ bias, int M, const int* __restrict__ Mptr,
+                                          int Nc, int K, int flags, int ksplit, float* __restrict__ part,
+                                          int block_id, float* __restrict__ smem) {
   constexpr int BK = 32;
   constexpr int LS = BK + 4;  // padded LDS row stride (floats)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
   constexpr int STAGE = (BM + BN) * LS;
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * STAGE];
 
   int Meff = M;
   if (Mptr) {
@@ -43,7 +41,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
     Meff = md < M ? md : M;
   }
   const int tiles_n = Nc / BN;
-  const int tile = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+  const int tile = block_id / ksplit, ks = block_id % ksplit;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
   if (row0 >= Meff) return;
@@ -181,6 +179,35 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 #undef VSN_SSTORE
 }
 
+template <int BM, int BN, int WM, int WN, bool DB>
+__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
+                                              const float* __restrict__ Bt, int ldb,
+                                              float* __restrict__ C, int ldc,
+                                              const float* __restrict__ bias, int M,
+                                              const int* __restrict__ Mptr, int Nc, int K, int flags,
+                                              int ksplit, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * 36];
+  gemm_body<BM, BN, WM, WN, DB>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
+                                (int)blockIdx.x, smem);
+}
+
+// Several independent products in ONE launch (64x64 tiles): block -> (problem, tile).  Used for the
+// per-layer groups {qkv, vector projections, edge linears}, {s_proj, o_proj}, {dX products}: on a
+// single-protein MD step the small members (N = a few hundred rows) cannot fill 256 CUs alone.
+__global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 36];
+  int b = (int)blockIdx.x, p = 0;
+#pragma unroll
+  for (int q = 0; q < GemmGroup::MAXP - 1; ++q)
+    if (p == q && q + 1 < g.n && b >= g.p[q].blocks) {
+      b -= g.p[q].blocks;
+      p = q + 1;
+    }
+  const GemmDesc& d = g.p[p];
+  gemm_body<64, 64, 2, 2, true>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K, d.flags,
+                                d.ksplit, d.part, b, smem);
+}
+
 // split-K epilogue: C (+)= sum_s part[s] (+ bias), fixed summation order
 __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float* __restrict__ C, int ldc,
                               const float* __restrict__ bias, int M, const int* __restrict__ Mptr, int Nc,
@@ -235,6 +262,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
     rec->variant = gemm_variant(M, Nc);
     rec->M = M;
     rec->dev_m = Mptr != nullptr;
+    rec->group_n = 0;
     rec->flops_per_row = 2.0 * (double)Nc * (double)K;
     rec->bytes_per_row = 4.0 * ((double)K + (double)Nc * ((flags & 1) ? 2.0 : 1.0));
     hipEventCreate(&rec->a);
@@ -287,6 +315,87 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
     hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, ks, C, ldc, bias,
                        M, Mptr, Nc, flags);
   }
+  return 0;
+}
+
+int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
+  // fall back to individual launches when the group would not use the 64x64 tiling anyway
+  bool groupable = n > 1 && n <= GemmGroup::MAXP;
+  long long tiles = 0;
+  for (int i = 0; i < n && groupable; ++i) {
+    const GemmDesc& d = descs[i];
+    if (d.M <= 0) continue;
+    if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) groupable = false;
+    if (gemm_variant(d.M, d.Nc) == 0) groupable = false;  // big enough to fill the chip alone
+    tiles += (long long)((d.M + 63) / 64) * (d.Nc / 64);
+  }
+  if (!groupable) {
+    for (int i = 0; i < n; ++i) {
+      const GemmDesc& d = descs[i];
+      int rc = launch_gemm(st, d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K, d.flags);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  GemmGroup g;
+  g.n = 0;
+  int grid = 0;
+  GemmProfiler::Rec* rec = nullptr;
+  if (tl_prof) {
+    tl_prof->recs.emplace_back();
+    rec = &tl_prof->recs.back();
+    rec->variant = 1;
+    rec->M = 1;
+    rec->dev_m = false;
+    rec->flops_per_row = 0;
+    rec->bytes_per_row = 0;
+    rec->group_n = 0;
+    hipEventCreate(&rec->a);
+    hipEventCreate(&rec->b);
+    hipEventRecord(rec->a, st);
+  }
+  // split-K members share the scratch buffer: carve it
+  size_t ws_off = 0;
+  GemmDesc red[GemmGroup::MAXP];
+  int nred = 0;
+  for (int i = 0; i < n; ++i) {
+    GemmDesc d = descs[i];
+    if (d.M <= 0) continue;
+    const int t = ((d.M + 63) / 64) * (d.Nc / 64);
+    int ks = 1;
+    if (t < 768 && d.K >= 512 && tl_splitk_ws && (d.ldc & 3) == 0) {
+      ks = (int)((1024 + tiles - 1) / tiles);
+      const int kmax = d.K / 128;
+      if (ks > kmax) ks = kmax;
+      if (ks > 8) ks = 8;
+      while (ks > 1 && ws_off + (size_t)ks * d.M * d.Nc > tl_splitk_elems) --ks;
+      if (ks < 1) ks = 1;
+    }
+    d.ksplit = ks;
+    d.part = ks > 1 ? tl_splitk_ws + ws_off : nullptr;
+    if (ks > 1) {
+      ws_off += (size_t)ks * d.M * d.Nc;
+      red[nred++] = d;
+    }
+    d.blocks = t * ks;
+    grid += d.blocks;
+    if (rec) {
+      rec->gM[rec->group_n] = d.M;
+      rec->gdev[rec->group_n] = d.Mptr != nullptr;
+      rec->gflops[rec->group_n] = 2.0 * d.Nc * d.K;
+      rec->gbytes[rec->group_n] = 4.0 * (d.K + d.Nc * ((d.flags & 1) ? 2.0 : 1.0));
+      rec->group_n++;
+    }
+    g.p[g.n++] = d;
+  }
+  if (g.n > 0) hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
+  for (int i = 0; i < nred; ++i) {
+    const GemmDesc& d = red[i];
+    long long n4 = (long long)d.M * (d.Nc / 4);
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d.part, d.ksplit, d.C,
+                       d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.flags);
+  }
+  if (rec) hipEventRecord(rec->b, st);
   return 0;
 }
 

@@ -46,12 +46,51 @@ struct Dims {
   const float* d;
 };
 
+struct GemmDesc {
+  const float* A;
+  const float* Bt;
+  float* C;
+  const float* bias;
+  const int* Mptr;
+  float* part;
+  int lda, ldb, ldc, M, Nc, K, flags, ksplit, blocks;
+};
+struct GemmGroup {
+  static constexpr int MAXP = 4;
+  GemmDesc p[MAXP];
+  int n;
+};
+inline GemmDesc gemm_desc(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias,
+                          int M, const int* Mptr, int Nc, int K, int flags) {
+  GemmDesc d;
+  d.A = A;
+  d.Bt = Bt;
+  d.C = C;
+  d.bias = bias;
+  d.Mptr = Mptr;
+  d.part = nullptr;
+  d.lda = lda;
+  d.ldb = ldb;
+  d.ldc = ldc;
+  d.M = M;
+  d.Nc = Nc;
+  d.K = K;
+  d.flags = flags;
+  d.ksplit = 1;
+  d.blocks = 0;
+  return d;
+}
+
 struct GemmProfiler {
   struct Rec {
     hipEvent_t a, b;
     int variant, M;
     bool dev_m;
     double flops_per_row, bytes_per_row;
+    int group_n;  // > 0: grouped launch, per-member rows/flops below
+    int gM[4];
+    bool gdev[4];
+    double gflops[4], gbytes[4];
   };
   std::vector<Rec> recs;
 };
@@ -60,6 +99,8 @@ void set_gemm_splitk_workspace(float* p, size_t elems);  // thread-local scratch
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
+// independent products in one launch (falls back to separate launches when not worthwhile)
+int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n);
 int launch_transpose(hipStream_t st, const float* in, float* out, int rows, int cols);
 
 int launch_graph(hipStream_t st, const GraphArgs& a);
