@@ -232,6 +232,7 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
+int g_splitk_tiles = 400;   // split-K only below this many output tiles (env VSN_SPLITK_TILES; swept on Chignolin: 0:297, 200:306, 400:306, 768:301, 1200:289 steps/s)
 int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
@@ -245,6 +246,14 @@ void set_gemm_splitk_workspace(float* p, size_t elems) {
 
 // 128x128 tiles only when they still give >= 4 workgroups per CU; otherwise the 4x finer
 // 64x64 tiling fills the 256 CUs better (one protein per MD step: M of a few thousand rows)
+static bool gemm_env_init() {
+  const char* e = getenv("VSN_GEMM_DB128");
+  if (e) g_gemm_db128 = atoi(e);
+  e = getenv("VSN_SPLITK_TILES");
+  if (e) g_splitk_tiles = atoi(e);
+  return true;
+}
+
 int gemm_variant(int M, int Nc) {
   if ((Nc % 128) == 0 && (long long)((M + 127) / 128) * (Nc / 128) >= 1024) return 0;
   if ((Nc % 64) == 0) return 1;
@@ -276,11 +285,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
       if (r) hipEventRecord(r->b, s);
     }
   } fin{rec, st};
-  static const bool env_init = [] {
-    const char* e = getenv("VSN_GEMM_DB128");
-    if (e) g_gemm_db128 = atoi(e);
-    return true;
-  }();
+  static const bool env_init = gemm_env_init();
   (void)env_init;
   const int variant = gemm_variant(M, Nc);
   const int bm = variant == 1 ? 64 : 128, bn = variant == 0 ? 128 : (variant == 1 ? 64 : 32);
@@ -288,7 +293,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   // split-K: few output tiles and a long K (the dX = dY.W products of the reverse pass on small
   // batches) would leave most CUs idle; cut K over `ks` workgroups and reduce deterministically.
   int ks = 1;
-  if (tiles < 768 && K >= 512 && tl_splitk_ws && (ldc & 3) == 0) {
+  if (tiles < g_splitk_tiles && K >= 512 && tl_splitk_ws && (ldc & 3) == 0) {
     ks = (1024 + tiles - 1) / tiles;
     const int kmax = K / 128;  // keep >= 4 k-tiles per split
     if (ks > kmax) ks = kmax;
@@ -319,6 +324,8 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
 }
 
 int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
+  static const bool env_init = gemm_env_init();
+  (void)env_init;
   // fall back to individual launches when the group would not use the 64x64 tiling anyway
   bool groupable = n > 1 && n <= GemmGroup::MAXP;
   long long tiles = 0;
@@ -363,7 +370,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     if (d.M <= 0) continue;
     const int t = ((d.M + 63) / 64) * (d.Nc / 64);
     int ks = 1;
-    if (t < 768 && d.K >= 512 && tl_splitk_ws && (d.ldc & 3) == 0) {
+    if (tiles < g_splitk_tiles && d.K >= 512 && tl_splitk_ws && (d.ldc & 3) == 0) {
       ks = (int)((1024 + tiles - 1) / tiles);
       const int kmax = d.K / 128;
       if (ks > kmax) ks = kmax;
