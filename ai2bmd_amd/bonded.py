@@ -107,6 +107,7 @@ class ShardedFragmentForces:
         self.send = torch.zeros(self.slot, dtype=torch.float32, device=device)
         self.recv = torch.zeros(world * self.slot, dtype=torch.float32, device=device)
         self.local_fn = self.combine_fn = None
+        self.direct = False  # True when local_fn writes straight into the exchange buffer
         self.energy_sign = torch.as_tensor(plan.energy_sign, device=device)
         nonempty = (plan.end - plan.start) > 0
         self._e_index = torch.as_tensor(
@@ -125,17 +126,15 @@ class ShardedFragmentForces:
     def step(self, prot_pos):
         """prot_pos [n_prot,3] on self.device -> (E 0-d tensor, F [n_prot,3] tensor)."""
         e_loc, f_loc = self.local_fn(prot_pos)
-        if self.world == 1:
-            buf = self.recv
-            buf[: self.local_rows * 3] = f_loc.reshape(-1)
-            buf[self.max_rows * 3: self.max_rows * 3 + len(self.local_start)] = e_loc
-        else:
+        stage = self.recv if self.world == 1 else self.send
+        if not self.direct:  # local_fn returned its own tensors: stage them into the exchange buffer
+            stage[: self.local_rows * 3] = f_loc.reshape(-1)
+            stage[self.max_rows * 3: self.max_rows * 3 + len(self.local_start)] = e_loc
+        if self.world > 1:
             import torch.distributed as dist
 
-            self.send[: self.local_rows * 3] = f_loc.reshape(-1)
-            self.send[self.max_rows * 3: self.max_rows * 3 + len(self.local_start)] = e_loc
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-            buf = self.recv
+        buf = self.recv
         F = self.combine_fn(buf)
         E = (buf[self._e_index] * self._e_sign).sum()
         return E, F
@@ -170,10 +169,13 @@ class ShardedFragmentForces:
             raise RuntimeError(f"vsn_combine_plan_create failed ({rc})")
         z_loc = torch.as_tensor(plan.z[lo:hi], dtype=torch.int64).to(dev)
         pos_loc = torch.empty(max(hi - lo, 1), 3, dtype=torch.float32, device=dev)
-        e_loc = torch.empty(max(self.f1 - self.f0, 1), dtype=torch.float32, device=dev)
-        f_loc = torch.empty(max(hi - lo, 1), 3, dtype=torch.float32, device=dev)
-        F_prot = torch.empty(plan.n_prot, 3, dtype=torch.float32, device=dev)
         nloc, bloc = hi - lo, self.f1 - self.f0
+        # the kernels write this rank's forces / energies straight into its slot of the exchange buffer
+        stage = self.recv if world == 1 else self.send
+        f_loc = stage[: max(nloc, 1) * 3].view(-1, 3)
+        e_loc = stage[self.max_rows * 3: self.max_rows * 3 + max(bloc, 1)]
+        self.direct = True
+        F_prot = torch.empty(plan.n_prot, 3, dtype=torch.float32, device=dev)
 
         def local_fn(prot_pos):
             st = torch.cuda.current_stream(dev)

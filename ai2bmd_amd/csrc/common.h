@@ -81,23 +81,33 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
   const int npb__ = (WPN) == 1 ? (int)(blockDim.x >> 6) : 1;                     \
   for (int node = blockIdx.x * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
 
-// sums acc[K][V] over the WPN waves of the workgroup into wave 0 (fixed order -> deterministic)
+// sums acc[K][V] over the WPN waves of the workgroup into wave 0 (fixed order -> deterministic).
+// Rows go through LDS in chunks of at most VSN_REDUCE_ROWS so the scratch stays <= 57 KB.
+#define VSN_REDUCE_ROWS 8
 template <int V, int K, int WPN>
 __device__ __forceinline__ void node_reduce(float (&acc)[K][V], float* __restrict__ smem, int lane, int sub) {
   if (WPN == 1) return;
-  __syncthreads();  // smem may still be read from the previous use
-  if (sub > 0) {
+  constexpr int KC = K < VSN_REDUCE_ROWS ? K : VSN_REDUCE_ROWS;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    __syncthreads();  // smem may still be read from the previous use
+    if (sub > 0) {
 #pragma unroll
-      for (int c = 0; c < V; ++c) smem[(((sub - 1) * K + k) * 64 + lane) * V + c] = acc[k][c];
-  }
-  __syncthreads();
-  if (sub == 0) {
-    for (int w = 1; w < WPN; ++w)
+      for (int k = 0; k < KC; ++k)
+        if (k0 + k < K) {
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+          for (int c = 0; c < V; ++c) smem[(((sub - 1) * KC + k) * 64 + lane) * V + c] = acc[k0 + k][c];
+        }
+    }
+    __syncthreads();
+    if (sub == 0) {
+      for (int w = 1; w < WPN; ++w)
 #pragma unroll
-        for (int c = 0; c < V; ++c) acc[k][c] += smem[(((w - 1) * K + k) * 64 + lane) * V + c];
+        for (int k = 0; k < KC; ++k)
+          if (k0 + k < K) {
+#pragma unroll
+            for (int c = 0; c < V; ++c) acc[k0 + k][c] += smem[(((w - 1) * KC + k) * 64 + lane) * V + c];
+          }
+    }
   }
 }

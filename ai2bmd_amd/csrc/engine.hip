@@ -661,8 +661,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   RC(launch_gemm(st, c->rbf, Rp, c->Wrbf, Rp, c->pp, 2 * H, c->brbf, Emax, EP, 2 * H, Rp, 0));
   RC(launch_embed_node(st, D, c->emb1, c->emb2, c->pp, c->cat));
   RC(launch_gemm(st, c->cat, 2 * H, c->Wc, 2 * H, c->x_emb, H, c->bc, N, nullptr, H, 2 * H, 0));
-  HIPCHK(c, hipMemcpyAsync(c->x, c->x_emb, (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
-  RC(launch_embed_edge(st, D, c->x_emb, c->pp, c->f, c->vec));
+  RC(launch_embed_edge(st, D, c->x_emb, c->pp, c->f, c->vec, c->x));
   // ---- ViS-MP layers ----
   for (int l = 0; l < L; ++l) {
     const bool last = (l == L - 1);
@@ -719,6 +718,9 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));
     // layer 0: the edge update and everything flowing into vec_in (== 0, position independent) vanish
     const bool l0 = (l == 0);
+    // (a fused walk over the out-edges doing the three source-side adjoints at once measured SLOWER
+    //  than three separate kernels - 609 vs 527 us on a 512-fragment batch, 53 vs 34 us on Chignolin:
+    //  these kernels are latency-bound and the fused one loses occupancy - so they stay separate)
     if (!last && !l0) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
     RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);

@@ -148,6 +148,65 @@ __global__ void k_graph_fill(const float* __restrict__ pos, const int* __restric
   }
 }
 
+// Small-fragment variant of pass 2 (n <= 64, every AI2BMD fragment): one wave per fragment,
+// positions and the dense n x n edge-id matrix live in LDS, so the by-source view needs no
+// searches: thread j just walks column j in ascending target order.
+__global__ __launch_bounds__(64) void k_graph_fill_small(const float* __restrict__ pos,
+                                                         const int* __restrict__ fstart,
+                                                         const int* __restrict__ fend,
+                                                         const int* __restrict__ rowptr, int* __restrict__ src,
+                                                         int* __restrict__ tgt, int* __restrict__ colptr,
+                                                         int* __restrict__ perm, float rc2, int max_nb) {
+  __shared__ float ps[64 * 3];
+  __shared__ int eid[64 * 65];  // eid[i*65 + j] = edge (j -> i) or -1 ; padded against bank conflicts
+  __shared__ int outdeg[64];
+  const int b = blockIdx.x;
+  const int s = fstart[b], n = fend[b] - s;
+  if (n <= 0) return;
+  const int t = threadIdx.x;
+  for (int k = t; k < 3 * n; k += 64) ps[k] = pos[3 * (size_t)s + k];
+  __syncthreads();
+  if (t < n) {
+    const int i = t;
+    int e = rowptr[s + i];
+    int cnt = 0;
+    const float xi = ps[3 * i], yi = ps[3 * i + 1], zi_ = ps[3 * i + 2];
+    for (int j = 0; j < n; ++j) {
+      float dx = ps[3 * j] - xi, dy = ps[3 * j + 1] - yi, dz = ps[3 * j + 2] - zi_;
+      float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      int id = -1;
+      if (d2 < rc2 && cnt < max_nb) {
+        src[e] = s + j;
+        tgt[e] = s + i;
+        id = e;
+        ++e;
+        ++cnt;
+      }
+      eid[i * 65 + j] = id;
+    }
+  }
+  __syncthreads();
+  int cnt = 0;
+  if (t < n)
+    for (int i = 0; i < n; ++i) cnt += eid[i * 65 + t] >= 0 ? 1 : 0;
+  outdeg[t] = t < n ? cnt : 0;
+  __syncthreads();
+  // exclusive prefix over the wave (n <= 64)
+  int incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    int v = __shfl_up(incl, o, 64);
+    if (t >= o) incl += v;
+  }
+  if (t < n) {
+    int out = rowptr[s] + incl - cnt;
+    colptr[s + t] = out;
+    for (int i = 0; i < n; ++i) {
+      const int e = eid[i * 65 + t];
+      if (e >= 0) perm[out++] = e;
+    }
+  }
+}
+
 // per-edge geometry: one thread per (edge, rbf index); Rp = padded rbf count (multiple of 32)
 __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ tgt,
                             const int* __restrict__ ecount, const float* __restrict__ means,
@@ -273,9 +332,14 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
                      a.max_nb);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
-  size_t shm = (size_t)(a.max_frag + 1) * sizeof(int);
-  hipLaunchKernelGGL(k_graph_fill, dim3(a.B), dim3(64), shm, st, a.pos, a.fstart, a.fend, a.rowptr, a.src, a.tgt,
-                     a.colptr, a.perm, a.rc2, a.max_nb);
+  if (a.max_frag <= 64) {
+    hipLaunchKernelGGL(k_graph_fill_small, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr, a.src,
+                       a.tgt, a.colptr, a.perm, a.rc2, a.max_nb);
+  } else {
+    size_t shm = (size_t)(a.max_frag + 1) * sizeof(int);
+    hipLaunchKernelGGL(k_graph_fill, dim3(a.B), dim3(64), shm, st, a.pos, a.fstart, a.fend, a.rowptr, a.src, a.tgt,
+                       a.colptr, a.perm, a.rc2, a.max_nb);
+  }
   long long tot = (long long)a.Emax * a.Rp;
   int blocks = (int)((tot + 255) / 256);
   if (blocks > 0)

@@ -38,17 +38,21 @@ __global__ void hk_mid(int N, int S, int H, const float* __restrict__ u0, const 
     vec1o[((size_t)i * S + s) * h2 + c] = gate * pv0[((size_t)i * S + s) * ldp + H + c];
 }
 
-// y_i = std * (wb1 . silu(a1b_i) + bb1) + atomref[z_i]
+// y_i = std * (wb1 . silu(a1b_i) + bb1) + atomref[z_i]   (one wave per node)
 __global__ void hk_final(int N, int h2, const float* __restrict__ a1b, const float* __restrict__ wb1, float bb1,
                          float stdv, const float* __restrict__ atomref, const int* __restrict__ zi,
                          float* __restrict__ y) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   float acc = 0.f;
-  for (int c = 0; c < h2; ++c) acc += silu_f(a1b[(size_t)i * h2 + c]) * wb1[c];
-  float v = (acc + bb1) * stdv;
-  if (atomref) v += atomref[zi[i]];
-  y[i] = v;
+  for (int c = lane; c < h2; c += 64) acc += silu_f(a1b[(size_t)i * h2 + c]) * wb1[c];
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = (acc + bb1) * stdv;
+    if (atomref) v += atomref[zi[i]];
+    y[i] = v;
+  }
 }
 
 __global__ void hk_energy(int B, const int* __restrict__ fstart, const int* __restrict__ fend,
@@ -128,7 +132,7 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
   hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.p1, h2, Bf.cat1, H,
                      h2);
   rc |= launch_gemm(st, Bf.cat1, H, W.Wa1, H, Bf.a1b, h2, W.ba1, N, nullptr, h2, H, 0);
-  hipLaunchKernelGGL(hk_final, dim3(nblk(N)), dim3(256), 0, st, N, h2, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
+  hipLaunchKernelGGL(hk_final, dim3((N + 3) / 4), dim3(256), 0, st, N, h2, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
                      D.zi, Bf.y);
   hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out);
   return rc;

@@ -110,7 +110,8 @@ int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, cons
 // ---- forward ----
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
                       float* cat);
-int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec);
+int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec,
+                      float* xcopy);
 int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
                      const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
                      int ldxh, float* vh);

@@ -52,7 +52,10 @@ static inline int node_grid(int N, int wpn) {
 }
 static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
 // LDS for node_reduce of K*V*64 floats per extra wave
-static inline size_t node_lds(int wpn, int K, int V) { return wpn == 1 ? 0 : (size_t)(wpn - 1) * K * V * 64 * 4; }
+static inline size_t node_lds(int wpn, int K, int V) {
+  const int kc = K < 8 ? K : 8;  // VSN_REDUCE_ROWS
+  return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
+}
 
 // ---- adjoint of the node update (visnet_block.py:271-274) ------------------------
 // g_o = [sum_s g_vec*vec3 | g_x*vec_dot | g_x] ; g_vp = [g_vdot*vec2 | g_vdot*vec1 | g_vec*o1]

@@ -50,7 +50,10 @@ static inline int node_grid(int N, int wpn) {
 }
 static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
 // LDS for node_reduce of K*V*64 floats per extra wave
-static inline size_t node_lds(int wpn, int K, int V) { return wpn == 1 ? 0 : (size_t)(wpn - 1) * K * V * 64 * 4; }
+static inline size_t node_lds(int wpn, int K, int V) {
+  const int kc = K < 8 ? K : 8;  // VSN_REDUCE_ROWS
+  return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
+}
 
 // ---- embeddings -------------------------------------------------------------
 // cat[i] = [ emb1[z_i] | sum_{j->i, j!=i} emb2[z_j] * phi_e * C_e ]   (utils.py:296-317)
@@ -91,12 +94,14 @@ template <int V, int S, int WPN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D, const float* __restrict__ x,
                                                                           const float* __restrict__ pp,
                                                                           float* __restrict__ f,
-                                                                          float* __restrict__ vec) {
+                                                                          float* __restrict__ vec,
+                                                                          float* __restrict__ xcopy) {
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     float xi[V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
+    if (sub == 0) strow<V>(xcopy + (size_t)i * H, lane, xi);  // running x of the layers starts as a copy
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = uni(D.src[e]);
       float xj[V], ps[V], o[V];
@@ -329,9 +334,10 @@ int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const fl
   VSN_LAUNCH(k_embed_node, 1, D, emb1, emb2, pp, cat);
   return 0;
 }
-int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec) {
+int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec,
+                      float* xcopy) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_embed_edge, 0, D, x, pp, f, vec);
+  VSN_LAUNCH(k_embed_edge, 0, D, x, pp, f, vec, xcopy);
   return 0;
 }
 int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
