@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvsn_hip.so")
+# VSN_LIB overrides the library (A/B builds during tuning); the default is the in-tree build
+LIB_PATH = os.environ.get("VSN_LIB") or os.path.join(_HERE, "libvsn_hip.so")
 
 
 class VsnHParams(C.Structure):

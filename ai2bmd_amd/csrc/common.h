@@ -4,6 +4,9 @@
 #include <stdint.h>
 
 #define VSN_WAVE 64
+#ifndef VSN_XCD_REMAP
+#define VSN_XCD_REMAP 1
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -69,6 +72,15 @@ __device__ __forceinline__ void strow(float* __restrict__ row, int lane, const f
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// XCD-aware block remap: the dispatcher places workgroup b on XCD b % 8, each XCD has its own L2.
+// Renumbering so that CONSECUTIVE logical blocks share an XCD keeps a fragment's node rows (which the
+// ~17 edges per node gather again and again) in ONE L2 instead of all eight.  Bijective for any grid.
+__device__ __forceinline__ int xcd_block(int b, int G) {
+  const int xcd = b & 7, idx = b >> 3;
+  const int q = G >> 3, r = G & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // Node loop.  WPN = waves cooperating on ONE node:
 //   WPN == 1 : one wave per node, (blockDim/64) nodes per workgroup (large batches);
 //   WPN  > 1 : the workgroup's WPN waves split the node's edge list (edge e0+sub, e0+sub+WPN, ...)
@@ -79,7 +91,8 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
   const int wv__ = threadIdx.x >> 6;                                             \
   const int sub = (WPN) == 1 ? 0 : wv__;                                         \
   const int npb__ = (WPN) == 1 ? (int)(blockDim.x >> 6) : 1;                     \
-  for (int node = blockIdx.x * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
+  const int blk__ = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;               \
+  for (int node = blk__ * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
 
 // sums acc[K][V] over the WPN waves of the workgroup into wave 0 (fixed order -> deterministic).
 // Rows go through LDS in chunks of at most VSN_REDUCE_ROWS so the scratch stays <= 57 KB.

@@ -78,7 +78,7 @@ struct vsn_ctx {
   bool debug = false;
   bool profile = false;
   double prof[3][4] = {{0}};  // per GEMM tile variant: launches, ms, flops, algorithmic bytes
-  int64_t max_chunk_edges = 262144;
+  int64_t max_chunk_edges = 1048576;  // ~84 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s)
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
   float *geo, *d, *rbf, *drbf;

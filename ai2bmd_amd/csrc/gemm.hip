@@ -41,10 +41,15 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     Meff = md < M ? md : M;
   }
   const int tiles_n = Nc / BN;
-  const int tile = block_id / ksplit, ks = block_id % ksplit;
+  // live blocks = those covering rows < Meff (the grid is sized by the host-side bound M).  The XCD-aware
+  // renumbering is done over the LIVE blocks only, so every XCD gets the same share of real work and the
+  // column tiles of one row tile (which share the A tile) meet in one L2.
+  const int live = ((Meff + BM - 1) / BM) * tiles_n * ksplit;
+  if (block_id >= live) return;
+  const int bid = VSN_XCD_REMAP ? xcd_block(block_id, live) : block_id;
+  const int tile = bid / ksplit, ks = bid % ksplit;
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int row0 = tm * BM, col0 = tn * BN;
-  if (row0 >= Meff) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -384,7 +389,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
       ws_off += (size_t)ks * d.M * d.Nc;
       red[nred++] = d;
     }
-    d.blocks = t * ks;
+    d.blocks = (t * ks + 7) & ~7;  // multiple of 8: local block id % 8 stays the XCD id
     grid += d.blocks;
     if (rec) {
       rec->gM[rec->group_n] = d.M;

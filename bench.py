@@ -83,6 +83,7 @@ def main():
                                                                "frag_batch"])
     ap.add_argument("--frags-per-gpu", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,6 +110,8 @@ def main():
     hp = default_hparams()
     sd = make_state_dict(hp, seed=2024)
     eng = ViSNetEngine(hp, sd, dev)
+    if args.chunk_edges:
+        eng.set_option("max_chunk_edges", args.chunk_edges)
     H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
 
     def barrier():

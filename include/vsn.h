@@ -67,7 +67,7 @@ int vsn_load_weight(vsn_handle h, const char* name, const void* ptr, const int64
  * required tensor is missing. */
 int vsn_finalize(vsn_handle h);
 
-/* Options: "max_chunk_edges" (workspace bound, default 262144), "debug" (1 = keep per-layer
+/* Options: "max_chunk_edges" (workspace bound, default 1048576 edge slots ~ 84 GB at H=256, L=9), "debug" (1 = keep per-layer
  * snapshots for vsn_debug_read), "profile" (1 = time every GEMM launch, see vsn_profile_read). */
 int vsn_set_option(vsn_handle h, const char* key, int64_t value);
 
