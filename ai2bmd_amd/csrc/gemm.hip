@@ -127,6 +127,9 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       __syncthreads();
       const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK + kbase;
       VSN_GLOAD(kn);
+      // keep the prefetch HERE: without this hipcc sinks the loads below the MFMA block (to shorten their
+      // live ranges), which exposes the full global-load latency once per k-tile
+      __builtin_amdgcn_sched_barrier(0);
     }
     const float* As = smem + (DB ? (kt & 1) : 0) * STAGE;
     const float* Bs = As + BM * LS;
@@ -154,6 +157,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       VSN_SSTORE((kt + 1) & 1);
       const int kn = (kt + 2 < nkt ? kt + 2 : kt + 1) * BK + kbase;
       VSN_GLOAD(kn);
+      __builtin_amdgcn_sched_barrier(0);  // issue the prefetch before the barrier / next MFMA block
     }
     __syncthreads();
   }
