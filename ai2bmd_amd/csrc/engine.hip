@@ -77,7 +77,7 @@ struct vsn_ctx {
   int capN = 0, capE = 0, capB = 0;
   bool debug = false;
   bool profile = false;
-  double prof[3][4] = {{0}};  // per GEMM tile variant: launches, ms, flops, algorithmic bytes
+  double prof[4][4] = {{0}};  // per GEMM kernel (128x128, 64x64, 128x32, grouped 64x64): launches, ms, flops, bytes
   int64_t max_chunk_edges = 1048576;  // ~84 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s)
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
@@ -842,10 +842,10 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
   return 0;
 }
 
-extern "C" int vsn_profile_read(vsn_handle c, double* out12) {
-  if (!c || !out12) return -22;
-  for (int v = 0; v < 3; ++v)
-    for (int k = 0; k < 4; ++k) out12[v * 4 + k] = c->prof[v][k];
+extern "C" int vsn_profile_read(vsn_handle c, double* out16) {
+  if (!c || !out16) return -22;
+  for (int v = 0; v < 4; ++v)
+    for (int k = 0; k < 4; ++k) out16[v * 4 + k] = c->prof[v][k];
   return 0;
 }
 

@@ -360,7 +360,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
   if (tl_prof) {
     tl_prof->recs.emplace_back();
     rec = &tl_prof->recs.back();
-    rec->variant = 1;
+    rec->variant = 3;  // k_gemm_group
     rec->M = 1;
     rec->dev_m = false;
     rec->flops_per_row = 0;

@@ -101,11 +101,11 @@ class ViSNetEngine:
 
     def profile_read(self):
         """-> {variant: dict(launches, ms, flops, bytes)} accumulated since set_option('profile', 1)."""
-        out = (C.c_double * 12)()
+        out = (C.c_double * 16)()
         self._check(self._L.vsn_profile_read(self._h, out))
-        names = ("gemm128x128", "gemm64x64", "gemm128x32")
+        names = ("k_gemm<128,128>", "k_gemm<64,64>", "k_gemm<128,32>", "k_gemm_group")
         return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], flops=out[4 * v + 2], bytes=out[4 * v + 3])
-                for v in range(3)}
+                for v in range(4)}
 
     def last_num_edges(self) -> int:
         return int(self._L.vsn_last_num_edges(self._h))

@@ -86,10 +86,11 @@ int vsn_forces(vsn_handle h, const int64_t* dev_z, const float* dev_pos, const i
                const int64_t* host_end, int64_t N, int64_t B, float* dev_e_out, float* dev_f_out, void* stream);
 
 /* With option "profile"=1 every GEMM launch is bracketed by HIP events on the launch stream;
- * this returns, per GEMM tile variant v in {0: 128x128, 1: 64x64, 2: 128x32},
+ * this returns, per GEMM kernel v in {0: k_gemm<128,128>, 1: k_gemm<64,64>, 2: k_gemm<128,32>,
+ * 3: k_gemm_group (64x64 tiles, several products per launch)},
  * out[4v..4v+3] = {launches, total ms, total algorithmic flops, total algorithmic bytes}
  * accumulated since the option was set. */
-int vsn_profile_read(vsn_handle h, double* out12);
+int vsn_profile_read(vsn_handle h, double* out16);
 
 /* Device-side edge count of the last chunk processed (synchronises). */
 int64_t vsn_last_num_edges(vsn_handle h);
