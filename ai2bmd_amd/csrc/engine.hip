@@ -715,7 +715,6 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     const LayerW& w = c->lw[l];
     LayerBuf& b = c->lb[l];
     RC(launch_bwd_node_update(st, D, c->g_x, c->g_vec, b.vp, b.o, c->g_o, c->g_vp));
-    RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));
     // layer 0: the edge update and everything flowing into vec_in (== 0, position independent) vanish
     const bool l0 = (l == 0);
     // (a fused walk over the out-edges doing the three source-side adjoints at once measured SLOWER
@@ -724,7 +723,13 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (!last && !l0) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
     RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
-    RC(launch_gemm(st, c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0));
+    {
+      // g_A = g_o.Wo (N rows, tiny) rides along with g_m = g_t.Ws (E rows) in one grouped launch
+      GemmDesc gd[2];
+      gd[0] = gemm_desc(c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0);
+      gd[1] = gemm_desc(c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0);
+      RC(launch_gemm_group(st, gd, 2));
+    }
     RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo));
     snapshot(c, st, "g_m", l, c->g_m, (size_t)Emax * H);
     snapshot(c, st, "g_pe", l, c->g_pe, (size_t)Emax * 3 * H);

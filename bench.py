@@ -96,6 +96,8 @@ def main():
                                                                "frag_batch"])
     ap.add_argument("--frags-per-gpu", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--integrator", default="hip", choices=["hip", "torch"],
+                    help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
     args = ap.parse_args()
 
@@ -116,7 +118,7 @@ def main():
 
     from ai2bmd_amd.bonded import ShardedFragmentForces
     from ai2bmd_amd.fragmentation import build_plan, fragment_positions
-    from ai2bmd_amd.md import Langevin
+    from ai2bmd_amd.md import Langevin, LangevinHIP
     from ai2bmd_amd.visnet_calculator import ViSNetEngine
     from oracle.weights import default_hparams, make_state_dict  # seeded weight generator only
 
@@ -140,7 +142,8 @@ def main():
         prot = load_protein(pname)
         plan = build_plan(prot)
         ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group)
-        md = Langevin(prot.numbers, prot.positions, ff.step, dev, seed=0, tether_k=5.0)
+        Integ = LangevinHIP if args.integrator == "hip" else Langevin
+        md = Integ(prot.numbers, prot.positions, ff.step, dev, seed=0, tether_k=5.0)
         for _ in range(args.warmup):
             md.step()
         barrier()

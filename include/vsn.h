@@ -128,6 +128,17 @@ void vsn_fragplan_destroy(vsn_fragplan_handle p);
 /* dev_prot_pos f32 [n_prot,3] -> dev_frag_pos f32 [n_frag_atoms,3] */
 int vsn_build_fragments(vsn_fragplan_handle p, const float* dev_prot_pos, float* dev_frag_pos, void* stream);
 
+/* ---- Langevin integrator step on the device (AIMD/simulator.py:96-116 -> ASE Langevin.step) ----
+ * ASE units (eV, Angstrom, amu): dt and friction in ASE time units, kT in eV.  tether_k > 0 adds
+ * -k (x - x0) to the forces (x0 = host_x0).  One step = vsn_md_half1, force evaluation at the new
+ * positions, vsn_md_half2. */
+typedef struct vsn_md* vsn_md_handle;
+int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n_atoms, const float* host_mass, float dt, float kT,
+                  float friction, uint64_t seed, float tether_k, const float* host_x0);
+void vsn_md_destroy(vsn_md_handle p);
+int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, void* stream);
+int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, const float* dev_F, void* stream);
+
 /* ---- work partitions (Calculators/device_strategy.py:84-127) ---- */
 /* Writes up to max_out triples (device_idx, frag_begin, frag_end); returns count. */
 int vsn_partition(const int64_t* host_start, const int64_t* host_end, int64_t B, int n_devices,
