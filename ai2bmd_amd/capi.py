@@ -93,6 +93,13 @@ def lib() -> C.CDLL:
     L.vsn_md_half1.restype = C.c_int
     L.vsn_md_half2.argtypes = [vp, f32p, f32p, f32p, vp]
     L.vsn_md_half2.restype = C.c_int
+    L.vsn_mm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    L.vsn_mm_create.restype = C.c_int
+    L.vsn_mm_destroy.argtypes = [vp]
+    L.vsn_mm_destroy.restype = None
+    L.vsn_mm_forces.argtypes = [vp, f32p, f32p, f32p, C.c_int, vp]
+    L.vsn_mm_forces.restype = C.c_int
     L.vsn_partition.argtypes = [i64p, i64p, C.c_int64, C.c_int, C.c_int64, i64p, C.c_int]
     L.vsn_partition.restype = C.c_int
     _lib = L
@@ -108,5 +115,5 @@ EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
     "vsn_forces", "vsn_profile_read", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
-    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2",
+    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
 ]

@@ -139,6 +139,17 @@ void vsn_md_destroy(vsn_md_handle p);
 int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, void* stream);
 int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, const float* dev_F, void* stream);
 
+/* ---- MM non-bonded term between atoms that do not share a dipeptide (Calculators/nonbonded.py:33-63) ----
+ * charges [e], sigma [nm], epsilon [kJ/mol] as OpenMM gives them (AIMD/protein.py:153-175);
+ * host_groups4 int32 [n,4]: ids of the dipeptides each atom belongs to, -1 padded (pairs whose id sets
+ * intersect are excluded, distancefrag.py:355-363).  Outputs in ASE units (eV, eV/Angstrom). */
+typedef struct vsn_mm* vsn_mm_handle;
+int vsn_mm_create(vsn_mm_handle* out, int device_id, int64_t n_atoms, const float* host_charge,
+                  const float* host_sigma, const float* host_epsilon, const int32_t* host_groups4);
+void vsn_mm_destroy(vsn_mm_handle p);
+/* dev_pos f32 [n,3] -> dev_e f32 [1], dev_f f32 [n,3] (added to dev_f when accumulate != 0) */
+int vsn_mm_forces(vsn_mm_handle p, const float* dev_pos, float* dev_e, float* dev_f, int accumulate, void* stream);
+
 /* ---- work partitions (Calculators/device_strategy.py:84-127) ---- */
 /* Writes up to max_out triples (device_idx, frag_begin, frag_end); returns count. */
 int vsn_partition(const int64_t* host_start, const int64_t* host_end, int64_t B, int n_devices,
