@@ -225,3 +225,32 @@ def test_vecnorm_variants_fresh_seed(lib_built, vn, lmax, H):
     m = ViSNetModel(hp, sd, device="cuda:0")
     e, f = m.dl_potential_loader(frag(z, pos, start, end))
     check(e, f, E64, F64)
+
+
+def test_full_size_batch_properties_and_chunk_boundaries(lib_built):
+    """BASELINE-sized batch (2048 fragments, ~40k atoms, 128x128 GEMM tiles): replicated fragments give
+    bit-identical results in every replica, independent of where the engine cuts its chunks, and replica 0
+    matches the fp64 oracle."""
+    hp = default_hparams()  # H=256, L=9
+    sd = make_state_dict(hp, seed=9)
+    z1, p1, s1, e1 = random_fragments(11, [27, 12])
+    reps = 1024
+    n1 = len(z1)
+    z = np.tile(z1, reps)
+    pos = np.tile(p1, (reps, 1))
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    e = e.reshape(reps, 2)
+    f = f.reshape(reps, n1, 3)
+    assert np.abs(e - e[0]).max() == 0.0 and np.abs(f - f[0]).max() == 0.0
+    E64, F64, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z1, p1, s1, e1)
+    check(e[0].reshape(-1, 1), f[0], E64, F64)
+    m.engine.set_option("max_chunk_edges", 100000)  # forces ~7 chunks with ragged boundaries
+    e2, f2 = m.dl_potential_loader(frag(z, pos, start, end))
+    # chunk size changes the tile variant / reduction grouping, not the math: fp32 round-off only
+    np.testing.assert_allclose(e2.reshape(reps, 2), e, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(f2.reshape(reps, n1, 3), f, rtol=0, atol=2e-5)
