@@ -22,6 +22,7 @@
 using namespace vsn;
 
 #define VSN_MAX_FRAG_ATOMS 16000
+#define VSN_GEO_W 24  // g_geo row: dE/dd (vector messages) 0..7, dE/dC 8, dE/dd (edge update) 16..23
 
 namespace {
 
@@ -93,6 +94,10 @@ struct vsn_ctx {
   float *g_pp, *g_n, *g_rbf, *g_geo, *g_ev;
   float* splitk;
   size_t splitk_elems = 0;
+  // second stream for work that is independent of the main per-layer chain (edge update and its adjoints)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = true;
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -134,6 +139,10 @@ extern "C" int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id)
   if (c->L < 1) return fail(c, -22, "num_layers must be >= 1");
   if (hp->vecnorm_type < 0 || hp->vecnorm_type > 2) return fail(c, -22, "unknown vecnorm_type");
   if (hipSetDevice(device_id) != hipSuccess) return fail(c, -19, "hipSetDevice failed (no MI355X visible?)");
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+    return fail(c, -5, "stream/event creation failed");
   return 0;
 }
 
@@ -142,6 +151,9 @@ extern "C" void vsn_destroy(vsn_handle c) {
   hipSetDevice(c->device);
   if (c->warena) hipFree(c->warena);
   if (c->ws.base) hipFree(c->ws.base);
+  if (c->side) hipStreamDestroy(c->side);
+  if (c->ev_fork) hipEventDestroy(c->ev_fork);
+  if (c->ev_join) hipEventDestroy(c->ev_join);
   for (auto& kv : c->snap)
     for (float* p : kv.second)
       if (p) hipFree(p);
@@ -174,6 +186,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->max_chunk_edges = value;
   } else if (k == "debug") {
     c->debug = value != 0;
+  } else if (k == "overlap") {
+    c->overlap = value != 0;
   } else if (k == "profile") {
     c->profile = value != 0;
     memset(c->prof, 0, sizeof(c->prof));
@@ -529,7 +543,7 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
   c->g_pp = a.take<float>(e * 2 * H);
   c->g_n = a.take<float>(n * H);
   c->g_rbf = a.take<float>(e * Rp);
-  c->g_geo = a.take<float>(e * 16);
+  c->g_geo = a.take<float>(e * VSN_GEO_W);
   c->g_ev = a.take<float>(e * 4);
   // split-K partials: up to 8 slices of the widest narrow output ([E,H] or [S*N,H])
   c->splitk_elems = 8 * std::max(e, n * S) * H;
@@ -654,7 +668,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (r__) return fail(c, r__, std::string("launch failed: ") + #call); \
   } while (0)
 
-  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, (size_t)Emax * 16 * sizeof(float), st));
+  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, (size_t)Emax * VSN_GEO_W * sizeof(float), st));
   HIPCHK(c, hipMemsetAsync(c->g_f, 0, (size_t)Emax * H * sizeof(float), st));
   RC(launch_graph(st, g));
   // ---- embeddings ----
@@ -683,6 +697,15 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       gd[ng++] = gemm_desc(c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, (last || l0) ? 2 * H : 3 * H, H, 0);
       RC(launch_gemm_group(st, gd, ng));
     }
+    // the edge update (f += df) only needs vp / pe / f: it runs on the side stream next to the
+    // attention -> s_proj/o_proj -> node update chain and is joined before the next layer reads f
+    const bool side_eu = c->overlap && !c->debug && !last && !l0;
+    if (side_eu) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      RC(launch_edge_update(c->side, D, b.vp, b.pe, c->f));
+      HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+    }
     RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
     snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
     snapshot(c, st, "A", l, c->A, (size_t)N * H);
@@ -693,7 +716,8 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       RC(launch_gemm_group(st, gd, 2));
     }
     RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec));
-    if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
+    if (side_eu) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+    else if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
   }
   snapshot(c, st, "x_in", L, c->x, (size_t)N * H);
   snapshot(c, st, "vec_in", L, c->vec, (size_t)N * S * H);
@@ -720,8 +744,21 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // (a fused walk over the out-edges doing the three source-side adjoints at once measured SLOWER
     //  than three separate kernels - 609 vs 527 us on a 512-fragment batch, 53 vs 34 us on Chignolin:
     //  these kernels are latency-bound and the fused one loses occupancy - so they stay separate)
-    if (!last && !l0) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
-    RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
+    // side stream: the edge-update adjoints (need g_f, vp, pe) and the source side of the vector messages
+    // (needs g_vec, tpre) do not depend on this layer's main chain; they are joined before the dX products.
+    // (edge_update_T accumulates its dE/dd into its own g_geo slots 16..23, so it cannot race vecmsg_T.)
+    const bool side_bw = c->overlap && !c->debug && !l0;
+    if (side_bw) {
+      HIPCHK(c, hipEventRecord(c->ev_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+      if (!last) RC(launch_bwd_edge_update(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
+      RC(launch_bwd_vecmsg_S(c->side, D, c->g_vec, b.tpre, c->g_vh));
+      HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+      RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, nullptr, c->g_geo));
+    } else {
+      if (!last && !l0) RC(launch_bwd_edge_update(st, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
+      RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
+    }
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
     {
       // g_A = g_o.Wo (N rows, tiny) rides along with g_m = g_t.Ws (E rows) in one grouped launch
@@ -736,6 +773,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);
     snapshot(c, st, "g_vp", l, c->g_vp, (size_t)N * S * 5 * H);
     snapshot(c, st, "g_A", l, c->g_A, (size_t)N * H);
+    if (side_bw) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     {
       GemmDesc gd[3];
       int ng = 0;
@@ -909,7 +947,7 @@ extern "C" int64_t vsn_debug_read(vsn_handle c, const char* name, int layer, voi
   TAP("g_n", c->g_n, N * H)
   TAP("g_pp", c->g_pp, e * 2 * H)
   TAP("g_rbf", c->g_rbf, e * Rp)
-  TAP("g_geo", c->g_geo, e * 16)
+  TAP("g_geo", c->g_geo, e * VSN_GEO_W)
   TAP("g_ev", c->g_ev, e * 4)
   if (L_ok) {
     const LayerBuf& b = c->lb[layer];

@@ -273,18 +273,21 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
 // and the unit-vector normalisation).  one thread per edge.
 __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restrict__ geo,
                            const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
-                           const float* __restrict__ g_geo /*[E,16]: g_d[8] at 0..7, g_C at 8*/, int S,
+                           const float* __restrict__ g_geo /*[E,24]: g_d 0..7 and 16..23, g_C at 8*/, int S,
                            float* __restrict__ g_ev /*[E,4]*/) {
   const int E = *ecount;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float* g = geo + (size_t)e * 8;
   const float dC = g[2], ux = g[3], uy = g[4], uz = g[5], rinv = g[6];
-  float gr = g_geo[(size_t)e * 16 + 8] * dC;
+  float gr = g_geo[(size_t)e * 24 + 8] * dC;
   const float* gb = g_rbf + (size_t)e * Rp;
   const float* db = drbf + (size_t)e * Rp;
   for (int k = 0; k < Rp; ++k) gr += gb[k] * db[k];
-  const float* gd = g_geo + (size_t)e * 16;
+  const float* gd0 = g_geo + (size_t)e * 24;
+  float gd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gd[k] = gd0[k] + gd0[16 + k];  // vector-message + edge-update shares
   const float s3 = 1.7320508075688772f;
   float gx = gd[0], gy = gd[1], gz = gd[2];
   if (S == 8) {

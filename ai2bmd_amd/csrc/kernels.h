@@ -127,6 +127,7 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
                            float* g_pe, float* g_vp, float* g_geo);
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
                       float* g_t, float* g_vh, float* g_geo);
+int launch_bwd_vecmsg_S(hipStream_t st, const Dims& D, const float* g_vec, const float* tpre, float* g_vh);
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo);
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh, const float* xn,

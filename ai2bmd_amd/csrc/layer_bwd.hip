@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
         p = wave_sum(p);
         if (lane == s) mine = p;
       }
-      if (lane < S) g_geo[(size_t)e * 16 + lane] += mine;
+      if (lane < S) g_geo[(size_t)e * 24 + 16 + lane] += mine;  // own slots: may run next to vecmsg_T
     }
     node_reduce<V, S, WPN>(gwt, smem, lane, sub);
     if (sub == 0) {
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
         p = wave_sum(p);
         if (lane == s) mine = p;
       }
-      if (lane < S) g_geo[(size_t)e * 16 + lane] += mine;
+      if (lane < S) g_geo[(size_t)e * 24 + lane] += mine;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gs1[c] *= d1[c];
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       const float gsat = ga * dssat * C;
       const bool head_lead = (lane & (lph - 1)) == 0;
       const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
-      if (lane == 0) g_geo[(size_t)e * 16 + 8] += gC;
+      if (lane == 0) g_geo[(size_t)e * 24 + 8] += gC;
       if (head_lead) {
         sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
         sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
       }
       strow<V>(g_pp + (size_t)e * 2 * H, lane, gph);
       p = wave_sum(p);
-      if (lane == 0) g_geo[(size_t)e * 16 + 8] += p;
+      if (lane == 0) g_geo[(size_t)e * 24 + 8] += p;
     }
   }
 }
@@ -589,6 +589,11 @@ int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const f
   if (D.N <= 0) return 0;
   VSN_LAUNCH(k_bwd_vecmsg_T, 0, D, g_vec, vh, tpre, g_t, g_geo);
   if (g_vh) VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
+  return 0;
+}
+int launch_bwd_vecmsg_S(hipStream_t st, const Dims& D, const float* g_vec, const float* tpre, float* g_vh) {
+  if (D.N <= 0) return 0;
+  VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
   return 0;
 }
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
