@@ -88,11 +88,22 @@ __device__ __forceinline__ int xcd_block(int b, int G) {
 //              e.g. one protein per MD step, where N waves cannot fill 256 CUs).
 #define VSN_NODE_LOOP(node, N, WPN)                                              \
   const int lane = threadIdx.x & 63;                                             \
-  const int wv__ = threadIdx.x >> 6;                                             \
+  const int wv__ = uni((int)(threadIdx.x >> 6)); /* wave id: make it an SGPR */  \
   const int sub = (WPN) == 1 ? 0 : wv__;                                         \
   const int npb__ = (WPN) == 1 ? (int)(blockDim.x >> 6) : 1;                     \
   const int blk__ = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;               \
   for (int node = blk__ * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
+
+// Edge-id cache: one coalesced load brings the ids of (up to) 64 consecutive edges of a node into the
+// wave's lanes; the edge loop then picks them with v_readlane instead of a dependent scalar load per edge
+// (halves the dependent-load chain of every edge iteration: id -> row instead of ptr -> id -> row).
+__device__ __forceinline__ int edge_cache_load(const int* __restrict__ ids, int e0, int e1, int lane) {
+  return (e0 + lane < e1) ? ids[e0 + lane] : 0;
+}
+__device__ __forceinline__ int edge_cache_get(int cache, const int* __restrict__ ids, int e, int e0) {
+  const int k = uni(e - e0);
+  return k < 64 ? __builtin_amdgcn_readlane(cache, k) : uni(ids[e]);
+}
 
 // sums acc[K][V] over the WPN waves of the workgroup into wave 0 (fixed order -> deterministic).
 // Rows go through LDS in chunks of at most VSN_REDUCE_ROWS so the scratch stays <= 57 KB.

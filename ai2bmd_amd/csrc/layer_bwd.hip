@@ -119,6 +119,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V], gwt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
       for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
     }
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float u2[S][V], dd[S];
       float dot[V], a1[V], a2[V];
 #pragma unroll
@@ -188,14 +189,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
   const int H = D.H;
   VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    const int permc = edge_cache_load(D.perm, t0, t1, lane);
+    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
     float gws[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) gws[s][c] = 0.f;
     for (int t = t0 + sub; t < t1; t += WPN) {
-      const int e = uni(D.perm[t]);
-      const int i = uni(D.tgt[e]);
+      const int e = edge_cache_get(permc, D.perm, t, t0);
+      const int i = uni(t - t0) < 64 ? __builtin_amdgcn_readlane(tgtc, uni(t - t0)) : uni(D.tgt[e]);
       float u1[S][V], dd[S], a1[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) a1[c] = 0.f;
@@ -236,11 +239,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float gv[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float t1[V], t2[V], s2[V], d1[V], d2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, t1);
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
@@ -288,14 +292,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
   const int H = D.H;
   VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    const int permc = edge_cache_load(D.perm, t0, t1, lane);
+    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
     float acc[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) acc[s][c] = 0.f;
     for (int t = t0 + sub; t < t1; t += WPN) {
-      const int e = uni(D.perm[t]);
-      const int i = uni(D.tgt[e]);
+      const int e = edge_cache_get(permc, D.perm, t, t0);
+      const int i = uni(t - t0) < 64 ? __builtin_amdgcn_readlane(tgtc, uni(t - t0)) : uni(D.tgt[e]);
       float s1[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
 #pragma unroll
@@ -331,13 +337,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
   const int lph = 64 / nh;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], gA[V], gq[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
     ldrow<V>(g_A + (size_t)i * H, lane, gA);
 #pragma unroll
     for (int c = 0; c < V; ++c) gq[0][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       const float C = D.geo[(size_t)e * 8 + 1];
       float k[V], v[V], pk[V], pv[V], gm[V];
       ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
@@ -395,12 +402,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
   const int lph = 64 / nh;
   VSN_NODE_LOOP(j, D.N, WPN) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    const int permc = edge_cache_load(D.perm, t0, t1, lane);
+    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
     float g2[2][V];
 #pragma unroll
     for (int c = 0; c < V; ++c) g2[0][c] = g2[1][c] = 0.f;
     for (int t = t0 + sub; t < t1; t += WPN) {
-      const int e = uni(D.perm[t]);
-      const int i = uni(D.tgt[e]);
+      const int e = edge_cache_get(permc, D.perm, t, t0);
+      const int i = uni(t - t0) < 64 ? __builtin_amdgcn_readlane(tgtc, uni(t - t0)) : uni(D.tgt[e]);
       float q[V], pk[V], pv[V], gm[V];
       ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
@@ -487,13 +496,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     const int t0 = uni(D.colptr[i]), t1 = uni(D.colptr[i + 1]);
     float xi[V], acc[1][V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float xj[V], ps[V], gf[V], gp[V];
       ldrow<V>(x + (size_t)j * H, lane, xj);
       ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
@@ -533,10 +543,11 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float gn[V];
     ldrow<V>(g_n + (size_t)i * H, lane, gn);
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float gph[V];
       if (j == i) {
 #pragma unroll

@@ -66,11 +66,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_node(Dims D
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float acc[1][V];
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       if (j == i) continue;
       const float C = D.geo[(size_t)e * 8 + 1];
       float em[V], ph[V];
@@ -99,11 +100,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float xi[V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
     if (sub == 0) strow<V>(xcopy + (size_t)i * H, lane, xi);  // running x of the layers starts as a copy
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float xj[V], ps[V], o[V];
       ldrow<V>(x + (size_t)j * H, lane, xj);
       ldrow<V>(pp + (size_t)e * 2 * H + H, lane, ps);
@@ -180,12 +182,13 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D,
   const int lph = 64 / D.nh;  // lanes per head
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], acc[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
 #pragma unroll
     for (int c = 0; c < V; ++c) acc[0][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       const float C = D.geo[(size_t)e * 8 + 1];
       float k[V], v[V], pk[V], pv[V], mv[V];
       ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
@@ -223,13 +226,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float Va[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
       for (int c = 0; c < V; ++c) Va[s][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float s1[V], s2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, s2);
@@ -288,11 +292,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims 
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, wt[s]);
     for (int e = e0 + sub; e < e1; e += WPN) {
-      const int j = uni(D.src[e]);
+      const int j = edge_cache_get(srcc, D.src, e, e0);
       float dot[V], a1[V], a2[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) dot[c] = a1[c] = a2[c] = 0.f;
