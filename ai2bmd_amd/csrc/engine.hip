@@ -697,6 +697,9 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       gd[ng++] = gemm_desc(c->f, H, w.We3, H, b.pe, 3 * H, w.be3, Emax, EP, (last || l0) ? 2 * H : 3 * H, H, 0);
       RC(launch_gemm_group(st, gd, ng));
     }
+    // (moving the vector-projection GEMMs vp = vh.Wv5 / g_vh += g_vp.Wv5 to the side stream as well was
+    //  measured: 350 -> 331 steps/s on Chignolin - two MFMA kernels sharing the CUs slow each other down more
+    //  than the shorter critical path gains - so only the latency-bound gather kernels are overlapped.)
     // the edge update (f += df) only needs vp / pe / f: it runs on the side stream next to the
     // attention -> s_proj/o_proj -> node update chain and is joined before the next layer reads f
     const bool side_eu = c->overlap && !c->debug && !last && !l0;
