@@ -93,3 +93,25 @@ def test_short_md_is_finite_and_reproducible(setup):
     x2, e2 = run()
     assert np.isfinite(x1).all() and (x1 == x2).all() and e1 == e2
     assert np.abs(x1 - prot.positions).max() < 1.0  # tethered: stays near the start geometry
+
+
+def test_two_handles_driven_from_two_threads(setup):
+    """DLBondedCalculator drives one model per device from a thread pool (bonded.py:75-77).  Two handles on
+    the same GPU stand in for two devices: partitions are evaluated concurrently and concatenated."""
+    from ai2bmd_amd.bonded import DLBondedCalculator
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+    from ai2bmd_amd.fragmentation import fragment_positions
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    hp, sd, prot, plan, model = setup
+    other = ViSNetModel(hp, sd, device="cuda:0")
+    pos = fragment_positions(plan, prot.positions).astype(np.float32)
+    fd = FragmentData(plan.z, pos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
+    one = DLBondedCalculator([model]).calculate(fd)
+    two = DLBondedCalculator([model, other], chunk_atoms=120)
+    two.set_work_partitions(fd.start, fd.end)
+    assert {d for d, _, _ in two._work} == {0, 1} and len(two._work) >= 3
+    for _ in range(3):
+        res = two.calculate(fd)
+        for a, b in zip(one, res):
+            np.testing.assert_allclose(b, a, rtol=0, atol=1e-5)
