@@ -98,6 +98,7 @@ struct vsn_ctx {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = true;
+  bool fuse_fwd = true, fuse_bwd_opt = true;
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -186,6 +187,10 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->max_chunk_edges = value;
   } else if (k == "debug") {
     c->debug = value != 0;
+  } else if (k == "fuse_fwd") {
+    c->fuse_fwd = value != 0;
+  } else if (k == "fuse_bwd") {
+    c->fuse_bwd_opt = value != 0;
   } else if (k == "overlap") {
     c->overlap = value != 0;
   } else if (k == "profile") {
@@ -684,9 +689,14 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "x_in", l, c->x, (size_t)N * H);
     snapshot(c, st, "vec_in", l, c->vec, (size_t)N * S * H);
     snapshot(c, st, "f_in", l, c->f, (size_t)Emax * H);
-    RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
-                        b.vh));
-    if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
+    // the norms of layer l > 0 (and of the read-out) were already produced by the node update of layer l-1
+    // when the fusion is active (vecnorm "none", not in debug mode)
+    const bool fuse_norm = c->fuse_fwd && c->hp.vecnorm_type == 0 && !c->debug;
+    if (!fuse_norm || l == 0) {
+      RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
+                          b.vh));
+      if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
+    }
     // layer 0: vec == 0 -> vec1..3, w_trg.v, w_src.v are 0 (buffer pre-cleared) and df == 0 (no f_proj needed)
     const bool l0 = (l == 0);
     {
@@ -718,30 +728,52 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       gd[1] = gemm_desc(c->A, H, w.Wo, H, b.o, 3 * H, w.bo, N, nullptr, 3 * H, H, 0);
       RC(launch_gemm_group(st, gd, 2));
     }
-    RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec));
+    {
+      NextNorm nn;
+      memset(&nn, 0, sizeof(nn));
+      if (fuse_norm) {
+        if (!last) {
+          const LayerW& wn = c->lw[l + 1];
+          LayerBuf& bn = c->lb[l + 1];
+          nn = NextNorm{wn.ln_g, wn.ln_b, wn.vln_w, bn.xn, bn.rstd, c->xh, bn.vh, H};
+        } else {
+          nn = NextNorm{c->on_g, c->on_b, c->vo_w, c->xn_o, c->rstd_o, c->hb.cat0, c->vo, 2 * H};
+        }
+      }
+      RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec, nn));
+    }
     if (side_eu) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
     else if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
   }
   snapshot(c, st, "x_in", L, c->x, (size_t)N * H);
   snapshot(c, st, "vec_in", L, c->vec, (size_t)N * S * H);
   // ---- read-out ----
-  RC(launch_node_norm(st, D, c->x, c->vec, c->on_g, c->on_b, c->vo_w, c->hp.vecnorm_type, c->xn_o, c->rstd_o,
-                      c->hb.cat0, 2 * H, c->vo));
-  if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, c->vo_w, c->vin_o, c->vo));
+  if (!(c->fuse_fwd && c->hp.vecnorm_type == 0 && !c->debug)) {
+    RC(launch_node_norm(st, D, c->x, c->vec, c->on_g, c->on_b, c->vo_w, c->hp.vecnorm_type, c->xn_o, c->rstd_o,
+                        c->hb.cat0, 2 * H, c->vo));
+    if (c->hp.vecnorm_type)
+      RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, c->vo_w, c->vin_o, c->vo));
+  }
   RC(launch_head_forward(st, D, c->hw, c->hb, c->vo, c->fstart, c->fend, Bn, e_out));
   // ---- reverse pass ----
   RC(launch_head_backward(st, D, c->hw, c->hb, c->g_vo));
-  RC(launch_bwd_node_norm(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w,
-                          c->hp.vecnorm_type, 0, c->g_x, c->g_vec));
-  if (c->hp.vecnorm_type)
-    RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, c->vin_o, c->vo_w, c->g_vo, 0, c->g_vec));
+  const bool fuse_bwd = c->fuse_bwd_opt && c->hp.vecnorm_type == 0 && !c->debug;
+  if (fuse_bwd) {
+    RC(launch_bwd_norm_update(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w, 0, c->g_x,
+                              c->g_vec, c->lb[L - 1].vp, c->lb[L - 1].o, c->g_o, c->g_vp));
+  } else {
+    RC(launch_bwd_node_norm(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w,
+                            c->hp.vecnorm_type, 0, c->g_x, c->g_vec));
+    if (c->hp.vecnorm_type)
+      RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, c->vin_o, c->vo_w, c->g_vo, 0, c->g_vec));
+  }
   snapshot(c, st, "g_x_in", L, c->g_x, (size_t)N * H);
   snapshot(c, st, "g_vec_in", L, c->g_vec, (size_t)N * S * H);
   for (int l = L - 1; l >= 0; --l) {
     const bool last = (l == L - 1);
     const LayerW& w = c->lw[l];
     LayerBuf& b = c->lb[l];
-    RC(launch_bwd_node_update(st, D, c->g_x, c->g_vec, b.vp, b.o, c->g_o, c->g_vp));
+    if (!fuse_bwd) RC(launch_bwd_node_update(st, D, c->g_x, c->g_vec, b.vp, b.o, c->g_o, c->g_vp));
     // layer 0: the edge update and everything flowing into vec_in (== 0, position independent) vanish
     const bool l0 = (l == 0);
     // (a fused walk over the out-edges doing the three source-side adjoints at once measured SLOWER
@@ -790,8 +822,12 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     }
     snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
-    RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
-                            l0 ? 3 /* skip the vec part */ : c->hp.vecnorm_type, 1, c->g_x, c->g_vec));
+    if (fuse_bwd && l > 0)  // norm adjoint of this layer + node-update adjoint of the layer below, one pass
+      RC(launch_bwd_norm_update(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, 1, c->g_x, c->g_vec,
+                                c->lb[l - 1].vp, c->lb[l - 1].o, c->g_o, c->g_vp));
+    else
+      RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
+                              l0 ? 3 /* skip the vec part */ : c->hp.vecnorm_type, 1, c->g_x, c->g_vec));
     // layer 0 normalises vec == 0, which does not depend on the positions: nothing to propagate
     if (c->hp.vecnorm_type && l > 0)
       RC(launch_vecnorm_bwd(st, N, H, S, c->hp.vecnorm_type, b.vin, w.vln_w, c->g_vh, 1, c->g_vec));

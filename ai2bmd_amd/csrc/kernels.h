@@ -116,8 +116,21 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
                      const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
                      int ldxh, float* vh);
 int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A);
+// LayerNorm + VecLayerNorm("none") of the NEXT layer (or the read-out) fused into the node update that
+// produces their input; xn == nullptr disables the fusion
+struct NextNorm {
+  const float *gamma, *beta, *wvec;
+  float *xn, *rstd, *xh, *vh;
+  int ldxh;
+};
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
-                       const float* o, float* x, float* vec);
+                       const float* o, float* x, float* vec, const NextNorm& nn);
+// adjoint of LayerNorm (+ VecLayerNorm "none") of layer l fused with the adjoint of the node update of
+// layer l-1 (both are node-local); see k_bwd_norm_update
+int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh,
+                           const float* xn, const float* rstd, const float* gamma, const float* wvec,
+                           int accumulate, float* g_x, float* g_vec, const float* vp, const float* o, float* g_o,
+                           float* g_vp);
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f);
 
 // ---- reverse ----

@@ -486,6 +486,97 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
   }
 }
 
+// ---- adjoint of LayerNorm + VecLayerNorm("none") of layer l  FUSED WITH  the adjoint of the node update
+// of layer l-1 (k_bwd_node_norm + k_bwd_node_update in one pass: both are node-local, g_x / g_vec of the
+// node stay in registers between the two)
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(256) void k_bwd_norm_update(Dims D, const float* __restrict__ g_xh, int ldg,
+                                                         const float* __restrict__ g_vh,
+                                                         const float* __restrict__ xn,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ wvec, int accumulate,
+                                                         float* __restrict__ g_x, float* __restrict__ g_vec,
+                                                         const float* __restrict__ vp, const float* __restrict__ o,
+                                                         float* __restrict__ g_o, float* __restrict__ g_vp) {
+  const int H = D.H;
+  const float invH = 1.0f / (float)H;
+  VSN_NODE_LOOP(i, D.N, 1) {
+    (void)sub;
+    float g[V], n[V], ga[V], w[V];
+    ldrow<V>(g_xh + (size_t)i * ldg, lane, g);
+    ldrow<V>(xn + (size_t)i * H, lane, n);
+    ldrow<V>(gamma, lane, ga);
+    ldrow<V>(wvec, lane, w);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      g[c] *= ga[c];
+      s1 += g[c];
+      s2 += g[c] * n[c];
+    }
+    const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+    const float rs = rstd[i];
+    float gx[V];
+    if (accumulate)
+      ldrow<V>(g_x + (size_t)i * H, lane, gx);
+    else {
+#pragma unroll
+      for (int c = 0; c < V; ++c) gx[c] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) gx[c] += rs * (g[c] - m1 - n[c] * m2);
+    strow<V>(g_x + (size_t)i * H, lane, gx);
+    // ---- node-update adjoint of the layer below, with this g_x and the g_vec rows produced on the fly
+    float o1[V], o2[V], gvd[V], vd[V], go1[V];
+    ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+    ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      gvd[c] = gx[c] * o2[c];
+      vd[c] = 0.f;
+      go1[c] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      float gv[V], ov[V];
+      ldrow<V>(g_vh + ((size_t)i * S + s) * H, lane, gv);
+      if (accumulate)
+        ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, ov);
+      else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) ov[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) ov[c] += gv[c] * w[c];
+      strow<V>(g_vec + ((size_t)i * S + s) * H, lane, ov);
+      const float* row = vp + ((size_t)i * S + s) * 5 * H;
+      float* grow = g_vp + ((size_t)i * S + s) * 5 * H;
+      float v1[V], v2[V], v3[V], t1[V], t2[V], t3[V];
+      ldrow<V>(row, lane, v1);
+      ldrow<V>(row + H, lane, v2);
+      ldrow<V>(row + 2 * H, lane, v3);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        vd[c] += v1[c] * v2[c];
+        go1[c] += ov[c] * v3[c];
+        t1[c] = gvd[c] * v2[c];
+        t2[c] = gvd[c] * v1[c];
+        t3[c] = ov[c] * o1[c];
+      }
+      strow<V>(grow, lane, t1);
+      strow<V>(grow + H, lane, t2);
+      strow<V>(grow + 2 * H, lane, t3);
+    }
+    float go2[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) go2[c] = gx[c] * vd[c];
+    strow<V>(g_o + (size_t)i * 3 * H, lane, go1);
+    strow<V>(g_o + (size_t)i * 3 * H + H, lane, go2);
+    strow<V>(g_o + (size_t)i * 3 * H + 2 * H, lane, gx);
+  }
+}
+
 // ---- adjoint of EdgeEmbedding (utils.py:331-337) -----------------------------------
 // g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
 template <int V, int S, int WPN>
@@ -621,6 +712,16 @@ int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int l
   VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_node_norm,
                   <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, norm_type,
                                                       accumulate, g_x, g_vec));
+  return 0;
+}
+int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh,
+                           const float* xn, const float* rstd, const float* gamma, const float* wvec,
+                           int accumulate, float* g_x, float* g_vec, const float* vp, const float* o, float* g_o,
+                           float* g_vp) {
+  if (D.N <= 0) return 0;
+  VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_norm_update,
+                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
+                                                      g_vec, vp, o, g_o, g_vp));
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
                                                                            const float* __restrict__ vp,
                                                                            const float* __restrict__ o,
                                                                            float* __restrict__ x,
-                                                                           float* __restrict__ vec) {
+                                                                           float* __restrict__ vec, NextNorm nn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
@@ -273,12 +273,44 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
           vv[c] += v3[c] * o1[c] + Va[s][c];
         }
         strow<V>(vec + ((size_t)i * S + s) * H, lane, vv);
+        if (nn.xn) {  // fused VecLayerNorm("none") of the NEXT layer / read-out: vh = vec * weight
+          float w[V];
+          ldrow<V>(nn.wvec, lane, w);
+#pragma unroll
+          for (int c = 0; c < V; ++c) vv[c] *= w[c];
+          strow<V>(nn.vh + ((size_t)i * S + s) * H, lane, vv);
+        }
       }
       float xv[V];
       ldrow<V>(x + (size_t)i * H, lane, xv);
 #pragma unroll
       for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
       strow<V>(x + (size_t)i * H, lane, xv);
+      if (nn.xn) {  // fused LayerNorm of the NEXT layer / read-out (same arithmetic as k_node_norm)
+        const float invH = 1.0f / (float)H;
+        float g[V], bta[V], sm_ = 0.f;
+        ldrow<V>(nn.gamma, lane, g);
+        ldrow<V>(nn.beta, lane, bta);
+#pragma unroll
+        for (int c = 0; c < V; ++c) sm_ += xv[c];
+        const float mean = wave_sum(sm_) * invH;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          xv[c] -= mean;
+          q += xv[c] * xv[c];
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) * invH + 1e-5f);
+        float n[V], hh[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          n[c] = xv[c] * rs;
+          hh[c] = n[c] * g[c] + bta[c];
+        }
+        strow<V>(nn.xn + (size_t)i * H, lane, n);
+        strow<V>(nn.xh + (size_t)i * nn.ldxh, lane, hh);
+        if (lane == 0) nn.rstd[i] = rs;
+      }
     }
   }
 }
@@ -360,9 +392,9 @@ int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const floa
   return 0;
 }
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
-                       const float* o, float* x, float* vec) {
+                       const float* o, float* x, float* vec, const NextNorm& nn) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_node_update, D.S, D, tpre, vh, vp, o, x, vec);
+  VSN_LAUNCH(k_node_update, D.S, D, tpre, vh, vp, o, x, vec, nn);
   return 0;
 }
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f) {

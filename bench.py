@@ -127,6 +127,9 @@ def main():
     eng = ViSNetEngine(hp, sd, dev)
     if args.chunk_edges:
         eng.set_option("max_chunk_edges", args.chunk_edges)
+    for kv in filter(None, os.environ.get("VSN_OPTS", "").split(",")):  # tuning aid: VSN_OPTS=fuse_fwd=0,overlap=0
+        k_, v_ = kv.split("=")
+        eng.set_option(k_, int(v_))
     H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
 
     def barrier():
