@@ -72,7 +72,6 @@ struct vsn_ctx {
   float *emb1, *emb2, *means, *betas, *Wrbf, *brbf, *WrbfT, *Wc, *bc, *WcnT, *on_g, *on_b, *vo_w;
   std::vector<LayerW> lw;
   HeadW hw;
-  float* d_atomref = nullptr;
   // workspace
   Arena ws;
   int capN = 0, capE = 0, capB = 0;

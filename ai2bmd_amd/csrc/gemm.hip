@@ -242,6 +242,7 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 int g_splitk_tiles = 400;   // split-K only below this many output tiles (env VSN_SPLITK_TILES; swept on Chignolin: 0:297, 200:306, 400:306, 768:301, 1200:289 steps/s)
+int g_gemm_force = 0;     // micro-benchmark aid (env VSN_GEMM_FORCE): force an experimental tile variant
 int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
@@ -260,6 +261,8 @@ static bool gemm_env_init() {
   if (e) g_gemm_db128 = atoi(e);
   e = getenv("VSN_SPLITK_TILES");
   if (e) g_splitk_tiles = atoi(e);
+  e = getenv("VSN_GEMM_FORCE");
+  if (e) g_gemm_force = atoi(e);
   return true;
 }
 
@@ -296,6 +299,24 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   } fin{rec, st};
   static const bool env_init = gemm_env_init();
   (void)env_init;
+  if (g_gemm_force >= 10 && !tl_prof) {
+    // experimental variants, single launch, no split-K
+#define VSN_TRY(ID, BM_, BN_, WM_, WN_, DB_)                                                                   \
+    if (g_gemm_force == ID && (Nc % BN_) == 0) {                                                                \
+      const int grid_ = ((M + BM_ - 1) / BM_) * (Nc / BN_);                                                     \
+      hipLaunchKernelGGL((k_gemm<BM_, BN_, WM_, WN_, DB_>), dim3(grid_), dim3(256), 0, st, A, lda, Bt, ldb, C,  \
+                         ldc, bias, M, Mptr, Nc, K, flags, 1, nullptr);                                         \
+      return 0;                                                                                                 \
+    }
+    VSN_TRY(10, 64, 64, 2, 2, false)
+    VSN_TRY(11, 64, 128, 2, 2, true)
+    VSN_TRY(12, 128, 64, 2, 2, true)
+    VSN_TRY(13, 64, 128, 2, 2, false)
+    VSN_TRY(14, 128, 64, 2, 2, false)
+    VSN_TRY(15, 64, 64, 2, 2, true)
+    VSN_TRY(16, 128, 128, 2, 2, false)
+#undef VSN_TRY
+  }
   const int variant = gemm_variant(M, Nc);
   const int bm = variant == 1 ? 64 : 128, bn = variant == 0 ? 128 : (variant == 1 ? 64 : 32);
   const int tiles = ((M + bm - 1) / bm) * (Nc / bn);

@@ -101,7 +101,6 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
 // independent products in one launch (falls back to separate launches when not worthwhile)
 int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n);
-int launch_transpose(hipStream_t st, const float* in, float* out, int rows, int cols);
 
 int launch_graph(hipStream_t st, const GraphArgs& a);
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,

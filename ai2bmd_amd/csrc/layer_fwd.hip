@@ -416,24 +416,4 @@ int launch_fill(hipStream_t st, float* p, size_t n, float v) {
   return 0;
 }
 
-__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
-  __shared__ float t[32][33];
-  int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
-  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
-    int r = r0 + k;
-    t[k][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
-  }
-  __syncthreads();
-  int orow = blockIdx.x * 32, ocol = r0 + threadIdx.x;
-  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
-    int rr = orow + k;
-    if (rr < cols && ocol < rows) out[(size_t)rr * rows + ocol] = t[threadIdx.x][k];
-  }
-}
-int launch_transpose(hipStream_t st, const float* in, float* out, int rows, int cols) {
-  dim3 g((cols + 31) / 32, (rows + 31) / 32), b(32, 8);
-  hipLaunchKernelGGL(k_transpose, g, b, 0, st, in, out, rows, cols);
-  return 0;
-}
-
 }  // namespace vsn
