@@ -1,0 +1,236 @@
+"""Cap-hydrogen relaxation plan (SURVEY.md 8f "next #1").
+
+Every MD step the reference relaxes the hydrogens it added when cutting dipeptides out of the chain with
+<= 10 L-BFGS iterations on an AMBER force field restricted to the terms that touch those hydrogens
+(/root/reference/src/Fragmentation/distancefrag.py:56-92 `get_fragments`,
+ /root/reference/src/Fragmentation/hydrogen/energies.py:8-61,211-242,
+ /root/reference/src/Fragmentation/hydrogen/ctable.py:168-244 term filters,
+ /root/reference/src/Fragmentation/hydrogen/topology.py:20-130 batching).
+
+This module builds, once per simulation, the flat term lists the HIP optimiser (`csrc/hydrogen.hip`)
+consumes:  which AMBER template atom every dipeptide row corresponds to (by atom NAME - the reference
+instead permutes rows into AMBER order with utils/seq_dict.pkl), the bond / angle / dihedral / non-bonded
+terms that involve a cap hydrogen with their parameters resolved, and, per cap hydrogen, the list of term
+occurrences (so gradients are gathered per atom in a fixed order, no atomics).
+ACE-NME fragments copy their atoms from the relaxed dipeptides (`alias`): ACE-NME k = the acetyl-like part of
+dipeptide k+1 + the N-methyl-amide-like part of dipeptide k (distancefrag.py:291-302).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .amber import TOPOLOGY_OF
+from .fragmentation import FragmentPlan, ProteinAtoms
+
+SCNB, SCEE = 1.2, 2.0  # HydrogenOptimizer defaults (energies.py:76-81); applied to ALL pairs there
+
+
+@dataclass
+class HydrogenPlan:
+    cap_rows: np.ndarray    # int64 [ncap] rows of the fragment batch that are optimised (dipeptide cap H)
+    alias: np.ndarray       # int64 [Nf] for ACE-NME rows: dipeptide row to copy from; -1 for dipeptide rows
+    tmpl_index: list        # per dipeptide: template atom index of every row
+    # terms (atom entries are fragment-batch rows)
+    bond: dict              # i, j, k, r0
+    angle: dict             # i, j, k, kf, th0
+    dihedral: dict          # i, j, k, l, kf, per, phase
+    pair: dict              # i, j, A, B, qq
+    occ_ptr: np.ndarray     # int32 [ncap+1]
+    occ_type: np.ndarray    # int32 : 0 bond, 1 angle, 2 dihedral, 3 pair
+    occ_term: np.ndarray    # int32 index into that type's arrays
+    occ_end: np.ndarray     # int32 : 0 = the cap atom is the FIRST atom of the term, 1 = the LAST
+    occ_w: np.ndarray       # float32 energy share of this occurrence (1 / number of cap atoms in the term)
+
+
+def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, b: int, tmpl) -> np.ndarray:
+    """Template atom index of every row of dipeptide fragment b (matching by atom name)."""
+    names = [str(n) for n in tmpl["atom_names"]]
+    nat = len(names)
+    rows = np.arange(plan.start[b], plan.end[b])
+    if len(rows) != nat:
+        raise ValueError(f"dipeptide {b}: {len(rows)} atoms, template has {nat}")
+    src = plan.src[rows]
+    d = b // 2
+    r = d + 2  # central residue number (1-based, ACE = 1)
+    out = -np.ones(nat, dtype=np.int64)
+    resnum = np.where(src >= 0, p.resnums[np.maximum(src, 0)], 0)
+    # cap hydrogens belong to the residue of their acceptor
+    capres = np.where(src < 0, p.resnums[np.maximum(plan.acceptor[rows], 0)], 0)
+    res_of_row = np.where(src >= 0, resnum, capres)
+    ace_names, nme_names = names[:6], names[-6:]
+    mid_names = names[6:-6]
+
+    def name_of(k):
+        return str(p.names[src[k]]) if src[k] >= 0 else "cap"
+
+    prev = [k for k in range(nat) if res_of_row[k] == r - 1]
+    own = [k for k in range(nat) if res_of_row[k] == r]
+    nxt = [k for k in range(nat) if res_of_row[k] == r + 1]
+    assert len(prev) == 6 and len(nxt) == 6 and len(own) == nat - 12, (b, len(prev), len(own), len(nxt))
+    # --- acetyl-like part: template H1 CH3 H2 H3 C O
+    if str(p.resnames[np.flatnonzero(p.resnums == r - 1)[0]]) == "ACE":
+        for k in prev:
+            out[k] = ace_names.index(name_of(k))
+    else:
+        hs = [0, 2, 3]
+        for k in prev:
+            nm = name_of(k)
+            if nm == "CA":
+                out[k] = 1
+            elif nm == "C":
+                out[k] = 4
+            elif nm == "O":
+                out[k] = 5
+            else:  # HA / HA2 / HA3 / cap -> the three equivalent methyl hydrogens, in row order
+                out[k] = hs.pop(0)
+    # --- the residue itself
+    for k in own:
+        nm = name_of(k)
+        if nm not in mid_names:
+            raise ValueError(f"atom {nm} of residue {r} not in the AMBER template {mid_names}")
+        out[k] = 6 + mid_names.index(nm)
+    # --- N-methyl-amide-like part: template N H CH3 HH31 HH32 HH33
+    base = nat - 6
+    if str(p.resnames[np.flatnonzero(p.resnums == r + 1)[0]]) == "NME":
+        for k in nxt:
+            out[k] = base + nme_names.index(name_of(k))
+    else:
+        hs = [3, 4, 5]
+        first_h_done = False
+        for k in nxt:
+            nm = name_of(k)
+            if nm == "N":
+                out[k] = base + 0
+            elif nm == "CA":
+                out[k] = base + 2
+            elif nm == "H" or (nm == "cap" and not first_h_done and plan.acceptor[rows[k]] >= 0
+                               and str(p.names[plan.acceptor[rows[k]]]) == "N"):
+                out[k] = base + 1  # amide H (for PRO: the cap placed on N)
+                first_h_done = True
+            else:
+                out[k] = base + hs.pop(0)
+    if sorted(out.tolist()) != list(range(nat)):
+        raise ValueError(f"dipeptide {b}: name matching is not a bijection")
+    return out
+
+
+def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> HydrogenPlan:
+    Nf = len(plan.z)
+    B = len(plan.start)
+    resname_of = {int(r): str(p.resnames[np.flatnonzero(p.resnums == r)[0]]) for r in set(p.resnums.tolist())}
+    bond = dict(i=[], j=[], k=[], r0=[])
+    angle = dict(i=[], j=[], k=[], kf=[], th0=[])
+    dih = dict(i=[], j=[], k=[], l=[], kf=[], per=[], phase=[])
+    pair = dict(i=[], j=[], A=[], B=[], qq=[])
+    tmpl_index = []
+    cap_rows = []
+    occ = {}  # cap row -> list of (type, term, end, ncap_in_term)
+
+    def add_occ(row, typ, term, end, ncap):
+        occ.setdefault(int(row), []).append((typ, term, end, ncap))
+
+    for b in range(0, B, 2):
+        d = b // 2
+        code = TOPOLOGY_OF[resname_of[d + 2]]
+        t = tables[code]
+        ti = template_index_of_dipeptide(p, plan, b, t)
+        tmpl_index.append(ti)
+        rows = np.arange(plan.start[b], plan.end[b])
+        row_of_tmpl = np.empty(len(rows), dtype=np.int64)
+        row_of_tmpl[ti] = rows
+        capmask_t = np.zeros(len(rows), dtype=bool)
+        capmask_t[ti[plan.src[rows] < 0]] = True  # template indices that are cap hydrogens
+        cap_rows.extend(rows[plan.src[rows] < 0].tolist())
+        # bonds / angles / dihedrals that touch a cap hydrogen (ctable.py:168-199)
+        for a, c, idx in t["bonds_inc_hydrogen"]:
+            if capmask_t[a] or capmask_t[c]:
+                term = len(bond["i"])
+                bond["i"].append(row_of_tmpl[a]); bond["j"].append(row_of_tmpl[c])
+                bond["k"].append(t["bond_force_constant"][idx]); bond["r0"].append(t["bond_equil_value"][idx])
+                n = int(capmask_t[a]) + int(capmask_t[c])
+                if capmask_t[a]:
+                    add_occ(row_of_tmpl[a], 0, term, 0, n)
+                if capmask_t[c]:
+                    add_occ(row_of_tmpl[c], 0, term, 1, n)
+        for a, m, c, idx in t["angles_inc_hydrogen"]:
+            if capmask_t[a] or capmask_t[m] or capmask_t[c]:
+                assert not capmask_t[m], "a cap hydrogen cannot be the apex of an angle"
+                term = len(angle["i"])
+                angle["i"].append(row_of_tmpl[a]); angle["j"].append(row_of_tmpl[m]); angle["k"].append(row_of_tmpl[c])
+                angle["kf"].append(t["angle_force_constant"][idx]); angle["th0"].append(t["angle_equil_value"][idx])
+                n = int(capmask_t[a]) + int(capmask_t[c])
+                if capmask_t[a]:
+                    add_occ(row_of_tmpl[a], 1, term, 0, n)
+                if capmask_t[c]:
+                    add_occ(row_of_tmpl[c], 1, term, 1, n)
+        for a, m1, m2, c, idx in t["dihedrals_inc_hydrogen"]:
+            if m2 < 0 or c < 0:  # ctable.py:198: improper / multi-term markers are dropped
+                continue
+            if capmask_t[a] or capmask_t[m1] or capmask_t[m2] or capmask_t[c]:
+                assert not capmask_t[m1] and not capmask_t[m2]
+                term = len(dih["i"])
+                dih["i"].append(row_of_tmpl[a]); dih["j"].append(row_of_tmpl[m1])
+                dih["k"].append(row_of_tmpl[m2]); dih["l"].append(row_of_tmpl[c])
+                dih["kf"].append(t["dihedral_force_constant"][idx]); dih["per"].append(t["dihedral_periodicity"][idx])
+                dih["phase"].append(t["dihedral_phase"][idx])
+                n = int(capmask_t[a]) + int(capmask_t[c])
+                if capmask_t[a]:
+                    add_occ(row_of_tmpl[a], 2, term, 0, n)
+                if capmask_t[c]:
+                    add_occ(row_of_tmpl[c], 2, term, 1, n)
+        # non-bonded pairs i < j with a cap hydrogen, minus AMBER's excluded list (ctable.py:201-230)
+        nat = t["natom"]
+        ptr = np.concatenate([[0], np.cumsum(t["number_excluded_atoms"])])
+        excluded = set()
+        for a in range(nat):
+            for c in t["excluded_atoms_list"][ptr[a]:ptr[a + 1]]:
+                excluded.add((a, int(c)))
+        for a in range(nat):
+            for c in range(a + 1, nat):
+                if not (capmask_t[a] or capmask_t[c]) or (a, c) in excluded:
+                    continue
+                li = t["nonbonded_parm_index"][t["ntypes"] * t["atom_type_idx"][a] + t["atom_type_idx"][c]]
+                term = len(pair["i"])
+                pair["i"].append(row_of_tmpl[a]); pair["j"].append(row_of_tmpl[c])
+                pair["A"].append(t["lennard_jones_acoef"][li]); pair["B"].append(t["lennard_jones_bcoef"][li])
+                pair["qq"].append(t["charge"][a] * t["charge"][c])
+                n = int(capmask_t[a]) + int(capmask_t[c])
+                if capmask_t[a]:
+                    add_occ(row_of_tmpl[a], 3, term, 0, n)
+                if capmask_t[c]:
+                    add_occ(row_of_tmpl[c], 3, term, 1, n)
+
+    cap_rows = np.asarray(cap_rows, dtype=np.int64)
+    occ_ptr = [0]
+    ot, oterm, oend, ow = [], [], [], []
+    for row in cap_rows:
+        for typ, term, end, n in occ.get(int(row), []):
+            ot.append(typ); oterm.append(term); oend.append(end); ow.append(1.0 / n)
+        occ_ptr.append(len(ot))
+
+    # ACE-NME rows alias the dipeptide rows they are cut from
+    alias = -np.ones(Nf, dtype=np.int64)
+    for b in range(1, B, 2):
+        k = b // 2  # ACE-NME k: acetyl part of dipeptide k+1 (its first-residue rows), amide part of dipeptide k
+        rows = np.arange(plan.start[b], plan.end[b])
+        dn = np.arange(plan.start[2 * (k + 1)], plan.end[2 * (k + 1)])  # dipeptide k+1
+        dp = np.arange(plan.start[2 * k], plan.end[2 * k])              # dipeptide k
+
+        def key(rw):
+            return (int(plan.src[rw]), int(plan.acceptor[rw]), int(plan.toward[rw]))
+
+        lut_n = {key(rw): rw for rw in dn}
+        lut_p = {key(rw): rw for rw in dp}
+        for j, rw in enumerate(rows):
+            lut = lut_n if j < 6 else lut_p
+            alias[rw] = lut[key(rw)]
+
+    f32 = lambda d_: {k_: np.asarray(v, dtype=np.int32 if k_ in "ijkl" else np.float32) for k_, v in d_.items()}
+    return HydrogenPlan(
+        cap_rows=cap_rows, alias=alias, tmpl_index=tmpl_index,
+        bond=f32(bond), angle=f32(angle), dihedral=f32(dih), pair=f32(pair),
+        occ_ptr=np.asarray(occ_ptr, np.int32), occ_type=np.asarray(ot, np.int32),
+        occ_term=np.asarray(oterm, np.int32), occ_end=np.asarray(oend, np.int32), occ_w=np.asarray(ow, np.float32),
+    )
