@@ -141,19 +141,23 @@ class ShardedFragmentForces:
 
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
-    def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None):
+    def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None):
+        """hydrogen: optional ai2bmd_amd.hydrogen.HydrogenPlan - relax the cap hydrogens every call like
+        DistanceFragment.get_fragments (distancefrag.py:76-82).  The relaxation couples all dipeptides, so with
+        it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard."""
         dev = engine.device
         self = cls(plan, rank, world, dev, group)
         L = capi.lib()
         lo, hi = self.atom_lo[rank], self.atom_hi[rank]
-        # fragment geometry plan restricted to this rank's rows
-        src = np.ascontiguousarray(plan.src[lo:hi])
-        acc = np.ascontiguousarray(plan.acceptor[lo:hi])
-        tow = np.ascontiguousarray(plan.toward[lo:hi])
-        ln = np.ascontiguousarray(plan.length[lo:hi], dtype=np.float32)
+        # fragment geometry plan restricted to this rank's rows (all rows when the caps are relaxed)
+        g_lo, g_hi = (0, len(plan.z)) if hydrogen is not None else (lo, hi)
+        src = np.ascontiguousarray(plan.src[g_lo:g_hi])
+        acc = np.ascontiguousarray(plan.acceptor[g_lo:g_hi])
+        tow = np.ascontiguousarray(plan.toward[g_lo:g_hi])
+        ln = np.ascontiguousarray(plan.length[g_lo:g_hi], dtype=np.float32)
         self._fp = C.c_void_p()
-        rc = L.vsn_fragplan_create(C.byref(self._fp), engine.index, hi - lo, capi.i64_ptr(src), capi.i64_ptr(acc),
-                                   capi.i64_ptr(tow), ln.ctypes.data_as(C.POINTER(C.c_float)))
+        rc = L.vsn_fragplan_create(C.byref(self._fp), engine.index, g_hi - g_lo, capi.i64_ptr(src),
+                                   capi.i64_ptr(acc), capi.i64_ptr(tow), ln.ctypes.data_as(C.POINTER(C.c_float)))
         if rc:
             raise RuntimeError(f"vsn_fragplan_create failed ({rc})")
         # the combine plan reads straight from the padded all-gather buffer (rows of 3 floats)
@@ -168,7 +172,14 @@ class ShardedFragmentForces:
         if rc:
             raise RuntimeError(f"vsn_combine_plan_create failed ({rc})")
         z_loc = torch.as_tensor(plan.z[lo:hi], dtype=torch.int64).to(dev)
-        pos_loc = torch.empty(max(hi - lo, 1), 3, dtype=torch.float32, device=dev)
+        pos_geo = torch.empty(max(g_hi - g_lo, 1), 3, dtype=torch.float32, device=dev)
+        pos_loc = pos_geo[lo - g_lo: max(hi - g_lo, lo - g_lo + 1)]
+        self.relaxer = None
+        if hydrogen is not None:
+            from .hydrogen import HydrogenRelaxer
+
+            self.relaxer = HydrogenRelaxer(hydrogen, len(plan.z), engine.index)
+        self.frag_pos = pos_geo
         nloc, bloc = hi - lo, self.f1 - self.f0
         # the kernels write this rank's forces / energies straight into its slot of the exchange buffer
         stage = self.recv if world == 1 else self.send
@@ -181,9 +192,11 @@ class ShardedFragmentForces:
             st = torch.cuda.current_stream(dev)
             if nloc:
                 rc_ = L.vsn_build_fragments(self._fp, C.c_void_p(prot_pos.data_ptr()),
-                                            C.c_void_p(pos_loc.data_ptr()), C.c_void_p(st.cuda_stream))
+                                            C.c_void_p(pos_geo.data_ptr()), C.c_void_p(st.cuda_stream))
                 if rc_:
                     raise RuntimeError(f"vsn_build_fragments failed ({rc_})")
+                if self.relaxer is not None:
+                    self.relaxer.run(pos_geo, st)
                 engine.forces_device(z_loc[:nloc], pos_loc[:nloc], self.local_start, self.local_end, e_loc[:bloc],
                                      f_loc[:nloc], stream=st)
             return e_loc[:bloc], f_loc[:nloc]
@@ -197,5 +210,5 @@ class ShardedFragmentForces:
             return F_prot
 
         self.local_fn, self.combine_fn = local_fn, combine_fn
-        self._keep = (z_loc, pos_loc, e_loc, f_loc, F_prot)
+        self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot)
         return self

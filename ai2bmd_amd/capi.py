@@ -29,6 +29,23 @@ class VsnHParams(C.Structure):
     ]
 
 
+class VsnHoptTerms(C.Structure):
+    _i32p, _f32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_int64)
+    _fields_ = [
+        ("n_rows", C.c_int64), ("n_cap", C.c_int32), ("cap_rows", _i64p), ("alias", _i64p),
+        ("n_bond", C.c_int32), ("bond_i", _i32p), ("bond_j", _i32p), ("bond_k", _f32p), ("bond_r0", _f32p),
+        ("n_angle", C.c_int32), ("angle_i", _i32p), ("angle_j", _i32p), ("angle_k", _i32p), ("angle_kf", _f32p),
+        ("angle_th0", _f32p),
+        ("n_dihedral", C.c_int32), ("dih_i", _i32p), ("dih_j", _i32p), ("dih_k", _i32p), ("dih_l", _i32p),
+        ("dih_kf", _f32p), ("dih_per", _f32p), ("dih_phase", _f32p),
+        ("n_pair", C.c_int32), ("pair_i", _i32p), ("pair_j", _i32p), ("pair_a", _f32p), ("pair_b", _f32p),
+        ("pair_qq", _f32p),
+        ("occ_ptr", _i32p), ("occ_type", _i32p), ("occ_term", _i32p), ("occ_end", _i32p), ("occ_w", _f32p),
+        ("max_iter", C.c_int32), ("lr", C.c_float), ("tolerance_grad", C.c_float), ("tolerance_change", C.c_float),
+        ("scnb", C.c_float), ("scee", C.c_float),
+    ]
+
+
 VECNORM = {"none": 0, "rms": 1, "max_min": 2}
 _lib = None
 
@@ -100,6 +117,14 @@ def lib() -> C.CDLL:
     L.vsn_mm_destroy.restype = None
     L.vsn_mm_forces.argtypes = [vp, f32p, f32p, f32p, C.c_int, vp]
     L.vsn_mm_forces.restype = C.c_int
+    L.vsn_hopt_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(VsnHoptTerms)]
+    L.vsn_hopt_create.restype = C.c_int
+    L.vsn_hopt_destroy.argtypes = [vp]
+    L.vsn_hopt_destroy.restype = None
+    L.vsn_hopt_run.argtypes = [vp, f32p, vp]
+    L.vsn_hopt_run.restype = C.c_int
+    L.vsn_hopt_stats.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double), vp]
+    L.vsn_hopt_stats.restype = C.c_int
     L.vsn_partition.argtypes = [i64p, i64p, C.c_int64, C.c_int, C.c_int64, i64p, C.c_int]
     L.vsn_partition.restype = C.c_int
     _lib = L
@@ -116,4 +141,5 @@ EXPORTS = [
     "vsn_forces", "vsn_profile_read", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
     "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
+    "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",
 ]

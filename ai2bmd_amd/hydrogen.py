@@ -234,3 +234,80 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
         occ_ptr=np.asarray(occ_ptr, np.int32), occ_type=np.asarray(ot, np.int32),
         occ_term=np.asarray(oterm, np.int32), occ_end=np.asarray(oend, np.int32), occ_w=np.asarray(ow, np.float32),
     )
+
+
+class HydrogenRelaxer:
+    """Device handle of the HIP optimiser (`vsn_hopt_*`, csrc/hydrogen.hip) for one HydrogenPlan."""
+
+    def __init__(self, hplan: HydrogenPlan, n_rows: int, device_index: int = 0, max_iter: int = 10):
+        import ctypes as C
+
+        from . import capi
+
+        self._C, self._L = C, capi.lib()
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        keep = []
+
+        def P(arr, ctype):
+            keep.append(arr)
+            return arr.ctypes.data_as(C.POINTER(ctype))
+
+        b, a, d, p = hplan.bond, hplan.angle, hplan.dihedral, hplan.pair
+        t = capi.VsnHoptTerms()
+        t.n_rows, t.n_cap = n_rows, len(hplan.cap_rows)
+        t.cap_rows, t.alias = P(i64(hplan.cap_rows), C.c_int64), P(i64(hplan.alias), C.c_int64)
+        t.n_bond = len(b["i"])
+        t.bond_i, t.bond_j = P(i32(b["i"]), C.c_int32), P(i32(b["j"]), C.c_int32)
+        t.bond_k, t.bond_r0 = P(f32(b["k"]), C.c_float), P(f32(b["r0"]), C.c_float)
+        t.n_angle = len(a["i"])
+        t.angle_i, t.angle_j, t.angle_k = (P(i32(a[k]), C.c_int32) for k in "ijk")
+        t.angle_kf, t.angle_th0 = P(f32(a["kf"]), C.c_float), P(f32(a["th0"]), C.c_float)
+        t.n_dihedral = len(d["i"])
+        t.dih_i, t.dih_j, t.dih_k, t.dih_l = (P(i32(d[k]), C.c_int32) for k in "ijkl")
+        t.dih_kf, t.dih_per, t.dih_phase = (P(f32(d[k]), C.c_float) for k in ("kf", "per", "phase"))
+        t.n_pair = len(p["i"])
+        t.pair_i, t.pair_j = P(i32(p["i"]), C.c_int32), P(i32(p["j"]), C.c_int32)
+        t.pair_a, t.pair_b, t.pair_qq = (P(f32(p[k]), C.c_float) for k in ("A", "B", "qq"))
+        t.occ_ptr, t.occ_type = P(i32(hplan.occ_ptr), C.c_int32), P(i32(hplan.occ_type), C.c_int32)
+        t.occ_term, t.occ_end = P(i32(hplan.occ_term), C.c_int32), P(i32(hplan.occ_end), C.c_int32)
+        t.occ_w = P(f32(hplan.occ_w), C.c_float)
+        t.max_iter, t.lr, t.tolerance_grad, t.tolerance_change = max_iter, 0.1, 0.1, 0.01
+        t.scnb, t.scee = SCNB, SCEE
+        self._h = C.c_void_p()
+        rc = self._L.vsn_hopt_create(C.byref(self._h), device_index, C.byref(t))
+        if rc:
+            raise RuntimeError(f"vsn_hopt_create failed ({rc})")
+        self.n_rows = n_rows
+
+    def run(self, frag_pos, stream=None):
+        """frag_pos: float32 [n_rows,3] device tensor, relaxed in place."""
+        import torch
+
+        C = self._C
+        assert frag_pos.is_cuda and frag_pos.dtype == torch.float32 and frag_pos.is_contiguous()
+        assert frag_pos.shape[0] == self.n_rows
+        st = stream if stream is not None else torch.cuda.current_stream(frag_pos.device)
+        rc = self._L.vsn_hopt_run(self._h, C.c_void_p(frag_pos.data_ptr()), C.c_void_p(st.cuda_stream))
+        if rc:
+            raise RuntimeError(f"vsn_hopt_run failed ({rc})")
+
+    def stats(self, stream=None):
+        import torch
+
+        C = self._C
+        st = stream if stream is not None else torch.cuda.current_stream()
+        ie, ll = (C.c_int32 * 2)(), (C.c_double * 2)()
+        rc = self._L.vsn_hopt_stats(self._h, ie, ll, C.c_void_p(st.cuda_stream))
+        if rc:
+            raise RuntimeError(f"vsn_hopt_stats failed ({rc})")
+        return dict(iterations=ie[0], evaluations=ie[1], loss_first=ll[0], loss_last=ll[1])
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._L.vsn_hopt_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--integrator", default="hip", choices=["hip", "torch"],
                     help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
+    ap.add_argument("--no-relax-caps", action="store_true",
+                    help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
     args = ap.parse_args()
 
@@ -144,7 +146,14 @@ def main():
         pname = args.workload[:-3]
         prot = load_protein(pname)
         plan = build_plan(prot)
-        ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group)
+        hplan = None
+        if not args.no_relax_caps:
+            from ai2bmd_amd.amber import load_tables
+            from ai2bmd_amd.hydrogen import build_hydrogen_plan
+
+            hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(ROOT, "tests", "golden",
+                                                                             "amber_tables.npz")))
+        ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
         Integ = LangevinHIP if args.integrator == "hip" else Langevin
         md = Integ(prot.numbers, prot.positions, ff.step, dev, seed=0, tether_k=5.0)
         for _ in range(args.warmup):
@@ -166,7 +175,8 @@ def main():
         E_edges = eng.last_num_edges()
         n_loc = ff.local_rows
         workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
-                    f"atoms, Langevin 1 fs 300 K friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
+                    f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}Langevin 1 fs 300 K "
+                    f"friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
                     f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
         scaling = "strong"
         units_per_step = 1

@@ -150,6 +150,35 @@ void vsn_mm_destroy(vsn_mm_handle p);
 /* dev_pos f32 [n,3] -> dev_e f32 [1], dev_f f32 [n,3] (added to dev_f when accumulate != 0) */
 int vsn_mm_forces(vsn_mm_handle p, const float* dev_pos, float* dev_e, float* dev_f, int accumulate, void* stream);
 
+/* ---- cap-hydrogen relaxation (Fragmentation/distancefrag.py:30-32,56-92 get_fragments ->
+ * hydrogen/energies.py:211-242 HydrogenOptimizer.optimize_hydrogen; term selection hydrogen/ctable.py:168-244) ----
+ * Flat term lists over rows of the fragment position array; every term touches at least one cap hydrogen, and a cap
+ * hydrogen is always the first or the last atom of a term.  occ_* is a CSR over cap hydrogens of (type 0 bond /
+ * 1 angle / 2 dihedral / 3 non-bonded pair, term index, end 0 first / 1 last, energy share 1/#caps in the term).
+ * Energies in kcal/mol as in the AMBER tables (charges pre-scaled by 18.2223). */
+typedef struct vsn_hopt_terms {
+  int64_t n_rows;                 /* rows of dev_frag_pos */
+  int32_t n_cap;
+  const int64_t* cap_rows;        /* [n_cap] rows that are optimised */
+  const int64_t* alias;           /* [n_rows] row to copy from after the relaxation (ACE-NME rows), -1 = none; or NULL */
+  int32_t n_bond;     const int32_t *bond_i, *bond_j;                 const float *bond_k, *bond_r0;
+  int32_t n_angle;    const int32_t *angle_i, *angle_j, *angle_k;     const float *angle_kf, *angle_th0;
+  int32_t n_dihedral; const int32_t *dih_i, *dih_j, *dih_k, *dih_l;   const float *dih_kf, *dih_per, *dih_phase;
+  int32_t n_pair;     const int32_t *pair_i, *pair_j;                 const float *pair_a, *pair_b, *pair_qq;
+  const int32_t *occ_ptr, *occ_type, *occ_term, *occ_end;             const float* occ_w;
+  int32_t max_iter;               /* 10  (distancefrag.py:30) ; <= 16 */
+  float lr, tolerance_grad, tolerance_change;   /* 0.1, 0.1, 0.01 (energies.py:232-238) */
+  float scnb, scee;               /* 1.2, 2.0 (energies.py:76-81) */
+} vsn_hopt_terms;
+typedef struct vsn_hopt* vsn_hopt_handle;
+int vsn_hopt_create(vsn_hopt_handle* out, int device_id, const vsn_hopt_terms* host_terms);
+void vsn_hopt_destroy(vsn_hopt_handle p);
+/* relaxes the cap rows of dev_frag_pos f32 [n_rows,3] in place (one L-BFGS .step), then applies `alias` */
+int vsn_hopt_run(vsn_hopt_handle p, float* dev_frag_pos, void* stream);
+/* synchronises `stream`; host_iters_evals int32[2] = {L-BFGS iterations, energy evaluations},
+ * host_loss_first_last f64[2] (either may be NULL) */
+int vsn_hopt_stats(vsn_hopt_handle p, int32_t* host_iters_evals, double* host_loss_first_last, void* stream);
+
 /* ---- work partitions (Calculators/device_strategy.py:84-127) ---- */
 /* Writes up to max_out triples (device_idx, frag_begin, frag_end); returns count. */
 int vsn_partition(const int64_t* host_start, const int64_t* host_end, int64_t B, int n_devices,

@@ -1,0 +1,93 @@
+"""Cap-hydrogen relaxation: AMBER tables, term plan, and the oracle against golden vectors produced by the
+reference's own HydrogenOptimizer (oracle/make_hydrogen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ai2bmd_amd.amber import TOPOLOGY_OF, load_tables
+from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, fragment_positions
+from ai2bmd_amd.hydrogen import build_hydrogen_plan
+from oracle.hydrogen_oracle import HydrogenOracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+PROTEINS = ["chig", "trpcage", "ww", "abd"]
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLD, f"protein_{name}.npz"))
+    p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
+                     positions=z["positions"])
+    plan = build_plan(p)
+    hplan = build_hydrogen_plan(p, plan, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    return p, plan, hplan, np.load(os.path.join(GOLD, f"hopt_{name}.npz"))
+
+
+def test_amber_tables_fixture():
+    tables = load_tables(os.path.join(GOLD, "amber_tables.npz"))
+    assert set(tables) == set(TOPOLOGY_OF.values())
+    aa = tables["AA"]
+    assert aa["natom"] == 22 and list(aa["atom_names"][:6]) == ["H1", "CH3", "H2", "H3", "C", "O"]
+    assert list(aa["atom_names"][-6:]) == ["N", "H", "CH3", "HH31", "HH32", "HH33"]
+    for t in tables.values():
+        n = t["natom"]
+        assert len(t["charge"]) == n and len(t["atom_type_idx"]) == n and t["number_excluded_atoms"].sum() == len(
+            t["excluded_atoms_list"])
+        assert t["bonds_inc_hydrogen"][:, :2].max() < n and t["angles_inc_hydrogen"][:, :3].max() < n
+        assert abs(t["charge"].sum() / 18.2223 - round(t["charge"].sum() / 18.2223)) < 1e-3  # integer net charge
+
+
+@pytest.mark.parametrize("name", PROTEINS)
+def test_plan_structure(name):
+    p, plan, hp, _ = load_case(name)
+    caps = np.flatnonzero((plan.src < 0) & np.repeat(plan.is_dipeptide, plan.end - plan.start))
+    assert (hp.cap_rows == caps).all()
+    # every cap hydrogen has exactly one bond, and is an END atom of every term it appears in
+    for c, row in enumerate(hp.cap_rows):
+        sl = slice(hp.occ_ptr[c], hp.occ_ptr[c + 1])
+        ty, term, end = hp.occ_type[sl], hp.occ_term[sl], hp.occ_end[sl]
+        assert (ty == 0).sum() == 1
+        for t_, k_, e_ in zip(ty, term, end):
+            tab = (hp.bond, hp.angle, hp.dihedral, hp.pair)[t_]
+            first, last = tab["i"][k_], tab["jkl"[t_ if t_ < 3 else 0]][k_]
+            assert (last if e_ else first) == row
+    # energy shares add up to one per term
+    for t_, tab in enumerate((hp.bond, hp.angle, hp.dihedral, hp.pair)):
+        share = np.zeros(len(tab["i"]))
+        np.add.at(share, hp.occ_term[hp.occ_type == t_], hp.occ_w[hp.occ_type == t_])
+        assert np.allclose(share, 1.0)
+    # ACE-NME rows alias dipeptide rows that carry the same atom: identical before relaxation
+    pos = fragment_positions(plan, p.positions)
+    ace = hp.alias >= 0
+    assert ace.sum() == 12 * (len(plan.start) // 2) and not ace[hp.cap_rows].any()
+    assert np.array_equal(pos[ace], pos[hp.alias[ace]])
+    assert (plan.z[ace] == plan.z[hp.alias[ace]]).all()
+    assert not np.repeat(plan.is_dipeptide, plan.end - plan.start)[ace].any()
+
+
+@pytest.mark.parametrize("name", PROTEINS)
+def test_oracle_matches_reference_optimizer(name):
+    """golden = /root/reference HydrogenOptimizer(max_iter=10).optimize_hydrogen on the same geometry."""
+    p, plan, hp, gold = load_case(name)
+    orc = HydrogenOracle(hp)
+    for tag in ("x0", "x1"):
+        pos = fragment_positions(plan, gold[f"{tag}_prot"]).astype(np.float32)
+        e0 = orc.energy(torch.as_tensor(pos)).numpy()
+        assert np.allclose(e0, gold[f"{tag}_e0"], rtol=2e-4, atol=2e-3)  # bond, angle, dihedral, vdw, elec
+        out = orc.relax(pos)
+        assert np.abs(out[hp.cap_rows] - gold[f"{tag}_caps"]).max() < 1e-5
+        not_cap = np.ones(len(pos), bool)
+        not_cap[hp.cap_rows] = False
+        assert np.array_equal(out[not_cap], pos[not_cap])
+        e1 = orc.energy(torch.as_tensor(out)).numpy()
+        assert np.allclose(e1, gold[f"{tag}_e1"], rtol=2e-4, atol=2e-3) and e1.sum() < e0.sum()
+
+
+def test_oracle_multi_iteration_descends():
+    p, plan, hp, _ = load_case("chig")
+    pos = fragment_positions(plan, p.positions).astype(np.float32)
+    rng = np.random.default_rng(5)
+    pos[hp.cap_rows[:3]] += 0.3 * rng.standard_normal((3, 3)).astype(np.float32)
+    out, trace = HydrogenOracle(hp).relax(pos, return_trace=True)
+    assert len(trace) > 3 and all(b < a for a, b in zip(trace, trace[1:]))
