@@ -109,8 +109,8 @@ __device__ __forceinline__ void occurrence(const int4 I, const float4 P, const V
     const float phi = atan2f(dot(m1, n2), dot(n1, n2));
     const float arg = P.y * phi - P.z;
     e = 0.5f * P.x * (1.0f + cosf(arg));
-    const float dE = -0.5f * P.x * P.y * sinf(arg);  // dE/dphi ; dphi/dx_0 = -|w0| a1 / |a1|^2
-    const float s = -dE * w0n / a1sq;
+    const float dE = -0.5f * P.x * P.y * sinf(arg);  // dE/dphi ; dphi/dx_0 = +|w0| a1 / |a1|^2 (a1 = w1 x w0)
+    const float s = dE * w0n / a1sq;
     g = {s * a1.x, s * a1.y, s * a1.z};
   } else {  // non-bonded pair: A/r^12 - B/r^6 (already / scnb) + qq / r (already / scee)
     const V3 dv = sub(x, ld3(pos, I.y));
