@@ -46,7 +46,34 @@ def by_grid(path, pattern):
         print(f"\"{n[:60]}\",{g},{c},{a:.0f},{mn}")
 
 
+def busy(path, lo=0.5, hi=1.0):
+    """GPU busy fraction over the [lo, hi] fraction of the trace: union of kernel intervals / wall span"""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    iv = sorted(cur.execute(f"select start, end from {disp}"))
+    t0, t1 = iv[0][0], max(e for _, e in iv)
+    a, b = t0 + int((t1 - t0) * lo), t0 + int((t1 - t0) * hi)
+    iv = [(s, e) for s, e in iv if a <= s <= b]
+    union, summ, cur_s, cur_e = 0, 0, iv[0][0], iv[0][1]
+    for s, e in iv:
+        summ += e - s
+        if s > cur_e:
+            union += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    union += cur_e - cur_s
+    span = max(e for _, e in iv) - iv[0][0]
+    print(f"dispatches {len(iv)} span_ms {span / 1e6:.3f} busy_union_ms {union / 1e6:.3f} "
+          f"sum_kernel_ms {summ / 1e6:.3f} busy_frac {union / span:.3f}")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--busy":
+        busy(sys.argv[1], *[float(v) for v in sys.argv[3:5]])
+        sys.exit(0)
     if len(sys.argv) > 2:
         by_grid(sys.argv[1], sys.argv[2])
     else:
