@@ -108,6 +108,7 @@ class ShardedFragmentForces:
         self.recv = torch.zeros(world * self.slot, dtype=torch.float32, device=device)
         self.local_fn = self.combine_fn = None
         self.direct = False  # True when local_fn writes straight into the exchange buffer
+        self.emulate = False
         self.energy_sign = torch.as_tensor(plan.energy_sign, device=device)
         nonempty = (plan.end - plan.start) > 0
         self._e_index = torch.as_tensor(
@@ -130,7 +131,11 @@ class ShardedFragmentForces:
         if not self.direct:  # local_fn returned its own tensors: stage them into the exchange buffer
             stage[: self.local_rows * 3] = f_loc.reshape(-1)
             stage[self.max_rows * 3: self.max_rows * 3 + len(self.local_start)] = e_loc
-        if self.world > 1:
+        if self.world > 1 and self.emulate:
+            # single-process stand-in for one rank of a `world`-rank job (tuning aid: per-rank step time at that
+            # shard size on a 1-GPU box); the other ranks' slots stay zero
+            self.recv[self.rank * self.slot:(self.rank + 1) * self.slot] = self.send
+        elif self.world > 1:
             import torch.distributed as dist
 
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)

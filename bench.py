@@ -100,6 +100,8 @@ def main():
                     help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
     ap.add_argument("--no-relax-caps", action="store_true",
                     help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
+    ap.add_argument("--emulate-shard", default="", help="tuning aid, single process: 'r/w' = time rank r's share of a "
+                    "w-rank MD job without the collective (not a valid bench line)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
     args = ap.parse_args()
 
@@ -153,7 +155,12 @@ def main():
 
             hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(ROOT, "tests", "golden",
                                                                              "amber_tables.npz")))
-        ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
+        if args.emulate_shard:
+            er, ew = (int(v) for v in args.emulate_shard.split("/"))
+            ff = ShardedFragmentForces.for_engine(eng, plan, rank=er, world=ew, hydrogen=hplan)
+            ff.emulate = True
+        else:
+            ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
         Integ = LangevinHIP if args.integrator == "hip" else Langevin
         md = Integ(prot.numbers, prot.positions, ff.step, dev, seed=0, tether_k=5.0)
         for _ in range(args.warmup):

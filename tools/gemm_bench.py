@@ -22,6 +22,10 @@ SHAPES = [
 ]
 
 
+if os.environ.get("GEMM_SHAPES"):  # "M,Nc,K;M,Nc,K;..."
+    SHAPES = [tuple(int(v) for v in t.split(",")) + ("custom",) for t in os.environ["GEMM_SHAPES"].split(";")]
+
+
 def main():
     hp = default_hparams(embedding_dimension=64, num_layers=1)
     eng = ViSNetEngine(hp, make_state_dict(hp, seed=1), "cuda:0")
