@@ -22,7 +22,9 @@
 
 namespace vsn {
 
-template <int BM, int BN, int WM, int WN, bool DB>
+// SILU: apply silu() to A on its way into LDS (one product of the read-out head); a template parameter so that
+// the ~250 VALU instructions of the exact sigmoid are not sitting in the k-loop of every other product.
+template <int BM, int BN, int WM, int WN, bool DB, bool SILU = false>
 __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
                                           int ldb, float* __restrict__ C, int ldc,
                                           const float* __restrict__ bias, int M, const int* __restrict__ Mptr,
@@ -55,7 +57,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  const bool silu_a = (flags & 2) != 0;
+  constexpr bool silu_a = SILU;
   // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce)
   const int nkt_all = K / BK;
   const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
@@ -188,7 +190,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 #undef VSN_SSTORE
 }
 
-template <int BM, int BN, int WM, int WN, bool DB>
+template <int BM, int BN, int WM, int WN, bool DB, bool SILU = false>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
                                               const int* __restrict__ Mptr, int Nc, int K, int flags,
                                               int ksplit, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * 36];
-  gemm_body<BM, BN, WM, WN, DB>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
-                                (int)blockIdx.x, smem);
+  gemm_body<BM, BN, WM, WN, DB, SILU>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
+                                      (int)blockIdx.x, smem);
 }
 
 // Several independent products in ONE launch (64x64 tiles): block -> (problem, tile).  Used for the
@@ -317,6 +319,15 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
     VSN_TRY(16, 128, 128, 2, 2, false)
 #undef VSN_TRY
   }
+  if (flags & 2) {  // silu(A): its own instantiations, no split-K
+    if ((Nc % 64) == 0)
+      hipLaunchKernelGGL((k_gemm<64, 64, 2, 2, true, true>), dim3(((M + 63) / 64) * (Nc / 64)), dim3(256), 0, st, A, lda,
+                         Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, 1, nullptr);
+    else
+      hipLaunchKernelGGL((k_gemm<128, 32, 4, 1, true, true>), dim3(((M + 127) / 128) * (Nc / 32)), dim3(256), 0, st, A,
+                         lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, 1, nullptr);
+    return 0;
+  }
   const int variant = gemm_variant(M, Nc);
   const int bm = variant == 1 ? 64 : 128, bn = variant == 0 ? 128 : (variant == 1 ? 64 : 32);
   const int tiles = ((M + bm - 1) / bm) * (Nc / bn);
@@ -364,6 +375,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     if (d.M <= 0) continue;
     if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) groupable = false;
     if (gemm_variant(d.M, d.Nc) == 0) groupable = false;  // big enough to fill the chip alone
+    if (d.flags & 2) groupable = false;                   // silu(A) has its own kernels
     tiles += (long long)((d.M + 63) / 64) * (d.Nc / 64);
   }
   if (!groupable) {
