@@ -30,6 +30,16 @@ if __name__ == "__main__":
                 out[k][c] = sum(v) / len(v)
             out[k]["calls"] = len(dur[k])
             out[k]["avg_us"] = sum(dur[k]) / len(dur[k]) / 1e3
+    # derived: HBM bytes (2*FETCH_SIZE + WRITE_SIZE, KB; gfx950 reports half of wide coalesced reads) and GB/s,
+    # MFMA utilisation = MFMA busy cycles / (kernel cycles * 1024 SIMDs), kernel cycles = SQ_BUSY_CYCLES / 32 SEs
+    for v in out.values():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            v["hbm_MB"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024 / 1e6
+            v["hbm_GBps"] = v["hbm_MB"] / 1e3 / (v["avg_us"] * 1e-6)
+        if v.get("SQ_BUSY_CYCLES"):
+            v["clk_GHz"] = v["SQ_BUSY_CYCLES"] / 32 / (v["avg_us"] * 1e3)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+                v["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["SQ_BUSY_CYCLES"] / 32 * 1024)
     names = sorted({c for v in out.values() for c in v})
     print("kernel," + ",".join(names))
     for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("avg_us", 0) * kv[1].get("calls", 0)):

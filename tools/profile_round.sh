@@ -1,0 +1,32 @@
+#!/bin/bash
+# Collects the per-round rocprofv3 evidence on the GPU box and leaves small summaries under gpurun_out/<tag>/
+# (copy the ones to be judged into profiles/).   usage:  bash tools/profile_round.sh <tag>
+# Kernel traces and PMC passes are separate runs; PMC passes carry --kernel-trace only (no other trace domain).
+set -u
+R=$PWD
+OUT=$R/gpurun_out/${1:-round}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CH="python $R/bench.py --no-cpu-baseline"
+BA="python $R/bench.py --no-cpu-baseline --workload frag_batch --frags-per-gpu 4096"
+
+timeout 600 rocprofv3 --kernel-trace -d "$OUT/kt_chig" -o c -- $CH --steps 100 --warmup 10 > "$OUT/kt_chig.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace -d "$OUT/kt_batch" -o c -- $BA --steps 2 --warmup 1 > "$OUT/kt_batch.log" 2>&1
+for W in chig batch; do
+  DB=$(find "$OUT/kt_$W" -name "*.db" | head -1)
+  python "$R/tools/rocpd_stats.py" "$DB" > "$OUT/${W}_kernel_stats.csv"
+  python "$R/tools/rocpd_stats.py" "$DB" --busy 0.3 0.6 > "$OUT/${W}_busy.txt"
+  rm -rf "$OUT/kt_$W"
+done
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+  i=$((i + 1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_chig_$i" -o b -- $CH --steps 20 --warmup 3 > "$OUT/pmc_chig_$i.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_batch_$i" -o b -- $BA --steps 1 --warmup 1 > "$OUT/pmc_batch_$i.log" 2>&1
+done
+for W in chig batch; do
+  python "$R/tools/pmc_summary.py" "$OUT/pmc_${W}_1" "$OUT/pmc_${W}_2" "$OUT/pmc_${W}_3" > "$OUT/${W}_pmc.csv"
+  rm -rf "$OUT"/pmc_${W}_?
+done
+tail -n 1 "$OUT/kt_chig.log" | cut -c1-300
+ls -la "$OUT"

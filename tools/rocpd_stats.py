@@ -70,7 +70,32 @@ def busy(path, lo=0.5, hi=1.0):
           f"sum_kernel_ms {summ / 1e6:.3f} busy_frac {union / span:.3f}")
 
 
+def gaps(path, lo=0.3, hi=0.6):
+    """idle gaps between kernels (start - latest end so far) inside the [lo, hi] fraction of the trace"""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    iv = sorted(cur.execute(f"select start, end from {disp}"))
+    t0, t1 = iv[0][0], max(e for _, e in iv)
+    a, b = t0 + int((t1 - t0) * lo), t0 + int((t1 - t0) * hi)
+    iv = [(s, e) for s, e in iv if a <= s <= b]
+    g, cur_e = [], iv[0][1]
+    for s, e in iv[1:]:
+        if s > cur_e:
+            g.append(s - cur_e)
+        cur_e = max(cur_e, e)
+    g.sort()
+    n = len(g)
+    print(f"kernels {len(iv)} gaps {n} total_gap_ms {sum(g) / 1e6:.3f} span_ms {(iv[-1][1] - iv[0][0]) / 1e6:.3f}")
+    for q in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99):
+        print(f"  p{int(q * 100):02d} {g[int(q * (n - 1))] / 1e3:.2f} us")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+        gaps(sys.argv[1], *[float(v) for v in sys.argv[3:5]])
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--busy":
         busy(sys.argv[1], *[float(v) for v in sys.argv[3:5]])
         sys.exit(0)
