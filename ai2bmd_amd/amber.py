@@ -92,3 +92,38 @@ def load_tables(path):
         t["natom"] = int(t["natom"])
         t["ntypes"] = int(t["ntypes"])
     return out
+
+
+def protein_mm_parameters(prot, tables):
+    """Per-atom charge [e], sigma [nm], epsilon [kJ/mol] in the units the reference takes from OpenMM
+    (AIMD/protein.py:153-175 `charges`, `sigmas`, `epsilons`), looked up by (residue, atom name) in the ACE-X-NME
+    AMBER tables: charge / 18.2223, and from the diagonal Lennard-Jones coefficients A = 4 eps sigma^12,
+    B = 4 eps sigma^6 of the atom's type.  (OpenMM is not installed; the capped-dipeptide topologies carry the
+    standard residue charges, so interior residues get their usual AMBER values.)"""
+    n = len(prot.numbers)
+    q, sig, eps = np.zeros(n, np.float32), np.full(n, 0.1, np.float32), np.zeros(n, np.float32)
+    any_t = tables["AA"]
+
+    def lookup(t, idx):
+        ti = int(t["atom_type_idx"][idx])
+        li = int(t["nonbonded_parm_index"][t["ntypes"] * ti + ti])
+        a, b = float(t["lennard_jones_acoef"][li]), float(t["lennard_jones_bcoef"][li])
+        if a > 0 and b > 0:
+            return float(t["charge"][idx]) / 18.2223, 0.1 * (a / b) ** (1.0 / 6.0), 4.184 * b * b / (4.0 * a)
+        return float(t["charge"][idx]) / 18.2223, 0.1, 0.0
+
+    for i in range(n):
+        res, name = str(prot.resnames[i]), str(prot.names[i])
+        if res == "ACE":
+            t, names, lo, hi = any_t, list(any_t["atom_names"][:6]), 0, 6
+        elif res == "NME":
+            nat = any_t["natom"]
+            t, names, lo, hi = any_t, list(any_t["atom_names"][-6:]), nat - 6, nat
+        else:
+            t = tables[TOPOLOGY_OF[res]]
+            nat = t["natom"]
+            names, lo, hi = list(t["atom_names"][6:nat - 6]), 6, nat - 6
+        if name not in names:
+            raise ValueError(f"atom {name} of residue {res} not in the AMBER template")
+        q[i], sig[i], eps[i] = lookup(t, lo + names.index(name))
+    return q, sig, eps

@@ -100,6 +100,8 @@ def main():
                     help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
     ap.add_argument("--no-relax-caps", action="store_true",
                     help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
+    ap.add_argument("--no-mm", action="store_true",
+                    help="skip the MM non-bonded term (reference: MMNonBondedCalculator added to the fragment forces)")
     ap.add_argument("--emulate-shard", default="", help="tuning aid, single process: 'r/w' = time rank r's share of a "
                     "w-rank MD job without the collective (not a valid bench line)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
@@ -161,8 +163,27 @@ def main():
             ff.emulate = True
         else:
             ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
+        force_fn = ff.step
+        if not args.no_mm:
+            # full AI2BMD potential = fragment (ViSNet) forces + MM Lennard-Jones/Coulomb between atoms that never
+            # share a dipeptide (Calculators/nonbonded.py:33-63); charges / sigma / epsilon from the AMBER tables
+            from types import SimpleNamespace
+
+            from ai2bmd_amd.amber import load_tables, protein_mm_parameters
+            from ai2bmd_amd.nonbonded import MMNonBondedCalculator
+
+            q_, s_, e_ = protein_mm_parameters(prot, load_tables(os.path.join(ROOT, "tests", "golden",
+                                                                                "amber_tables.npz")))
+            mm = MMNonBondedCalculator(dev)
+            mm.set_parameters(SimpleNamespace(charges=q_, sigmas=s_, epsilons=e_), plan)
+
+            def force_fn(pos):
+                E, F = ff.step(pos)
+                e_mm, _ = mm.forces_device(pos, f_out=F, accumulate=True)
+                return E + e_mm[0], F
+
         Integ = LangevinHIP if args.integrator == "hip" else Langevin
-        md = Integ(prot.numbers, prot.positions, ff.step, dev, seed=0, tether_k=5.0)
+        md = Integ(prot.numbers, prot.positions, force_fn, dev, seed=0, tether_k=5.0)
         for _ in range(args.warmup):
             md.step()
         barrier()
@@ -182,7 +203,8 @@ def main():
         E_edges = eng.last_num_edges()
         n_loc = ff.local_rows
         workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
-                    f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}Langevin 1 fs 300 K "
+                    f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
+                    f"{'+ MM non-bonded (LJ + Coulomb, AMBER parameters), ' if not args.no_mm else ''}Langevin 1 fs 300 K "
                     f"friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
                     f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
         scaling = "strong"

@@ -91,3 +91,16 @@ def test_oracle_multi_iteration_descends():
     pos[hp.cap_rows[:3]] += 0.3 * rng.standard_normal((3, 3)).astype(np.float32)
     out, trace = HydrogenOracle(hp).relax(pos, return_trace=True)
     assert len(trace) > 3 and all(b < a for a, b in zip(trace, trace[1:]))
+
+
+@pytest.mark.parametrize("name", PROTEINS)
+def test_mm_parameters_from_amber_tables(name):
+    from ai2bmd_amd.amber import protein_mm_parameters
+
+    p, plan, hp, _ = load_case(name)
+    q, sig, eps = protein_mm_parameters(p, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    assert abs(q.sum() - round(float(q.sum()))) < 2e-3          # residues carry integer charges
+    is_c = (p.numbers == 6) & (p.names == "CA")
+    assert np.allclose(sig[is_c], 0.339967, atol=1e-5)          # AMBER CT: Rmin/2 = 1.908 A
+    assert np.allclose(eps[is_c], 0.1094 * 4.184, rtol=1e-3)    #           eps = 0.1094 kcal/mol
+    assert (eps >= 0).all() and (sig > 0).all()
