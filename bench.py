@@ -126,7 +126,7 @@ def main():
     from ai2bmd_amd.fragmentation import build_plan, fragment_positions
     from ai2bmd_amd.md import Langevin, LangevinHIP
     from ai2bmd_amd.visnet_calculator import ViSNetEngine
-    from oracle.weights import default_hparams, make_state_dict  # seeded weight generator only
+    from ai2bmd_amd.synthetic import default_hparams, make_state_dict  # seeded weight generator
 
     hp = default_hparams()
     sd = make_state_dict(hp, seed=2024)

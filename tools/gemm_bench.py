@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ai2bmd_amd.visnet_calculator import ViSNetEngine  # noqa: E402
-from oracle.weights import default_hparams, make_state_dict  # noqa: E402
+from ai2bmd_amd.synthetic import default_hparams, make_state_dict  # noqa: E402
 
 SHAPES = [
     # (M, Nc, K, tag)

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 from bench import load_protein
 from ai2bmd_amd.fragmentation import build_plan, fragment_positions
 from ai2bmd_amd.visnet_calculator import ViSNetEngine
-from oracle.weights import default_hparams, make_state_dict
+from ai2bmd_amd.synthetic import default_hparams, make_state_dict
 dev="cuda:0"; hp=default_hparams(); sd=make_state_dict(hp, seed=2024)
 NF=int(sys.argv[1]) if len(sys.argv)>1 else 4096
 LANES=int(sys.argv[2]) if len(sys.argv)>2 else 2
