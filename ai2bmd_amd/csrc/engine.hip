@@ -96,7 +96,10 @@ struct vsn_ctx {
   // second stream for work that is independent of the main per-layer chain (edge update and its adjoints)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  bool overlap = true;
+  // bit 0: forward edge update on the side stream, bit 1: reverse-pass side work.  Measured on Chignolin
+  // (steps/s): none 339, forward only 327, reverse only 349, both 350 - a fork/join costs ~15 us of event latency,
+  // more than the 11-16 us forward edge update it hides, so only the reverse pass (50-60 us of side work per layer) forks.
+  int overlap = 2;
   bool fuse_fwd = true, fuse_bwd_opt = true;
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
@@ -191,7 +194,7 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
   } else if (k == "fuse_bwd") {
     c->fuse_bwd_opt = value != 0;
   } else if (k == "overlap") {
-    c->overlap = value != 0;
+    c->overlap = (int)value;
   } else if (k == "profile") {
     c->profile = value != 0;
     memset(c->prof, 0, sizeof(c->prof));
@@ -711,7 +714,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     //  than the shorter critical path gains - so only the latency-bound gather kernels are overlapped.)
     // the edge update (f += df) only needs vp / pe / f: it runs on the side stream next to the
     // attention -> s_proj/o_proj -> node update chain and is joined before the next layer reads f
-    const bool side_eu = c->overlap && !c->debug && !last && !l0;
+    const bool side_eu = (c->overlap & 1) && !c->debug && !last && !l0;
     if (side_eu) {
       HIPCHK(c, hipEventRecord(c->ev_fork, st));
       HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -781,7 +784,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // side stream: the edge-update adjoints (need g_f, vp, pe) and the source side of the vector messages
     // (needs g_vec, tpre) do not depend on this layer's main chain; they are joined before the dX products.
     // (edge_update_T accumulates its dE/dd into its own g_geo slots 16..23, so it cannot race vecmsg_T.)
-    const bool side_bw = c->overlap && !c->debug && !l0;
+    const bool side_bw = (c->overlap & 2) && !c->debug && !l0;
     if (side_bw) {
       HIPCHK(c, hipEventRecord(c->ev_fork, st));
       HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));

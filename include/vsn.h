@@ -68,7 +68,9 @@ int vsn_load_weight(vsn_handle h, const char* name, const void* ptr, const int64
 int vsn_finalize(vsn_handle h);
 
 /* Options: "max_chunk_edges" (workspace bound, default 1048576 edge slots ~ 84 GB at H=256, L=9), "debug" (1 = keep per-layer
- * snapshots for vsn_debug_read), "profile" (1 = time every GEMM launch, see vsn_profile_read). */
+ * snapshots for vsn_debug_read), "profile" (1 = time every GEMM launch, see vsn_profile_read), "overlap" (bit 0 / bit 1 =
+ * run the forward / reverse side work on a second HIP stream, default 2), "fuse_fwd", "fuse_bwd" (vertical fusions,
+ * default 1). */
 int vsn_set_option(vsn_handle h, const char* key, int64_t value);
 
 /*
