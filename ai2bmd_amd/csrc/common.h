@@ -86,13 +86,15 @@ __device__ __forceinline__ int xcd_block(int b, int G) {
 //   WPN  > 1 : the workgroup's WPN waves split the node's edge list (edge e0+sub, e0+sub+WPN, ...)
 //              and combine their partial sums through LDS in a fixed order (small batches,
 //              e.g. one protein per MD step, where N waves cannot fill 256 CUs).
-#define VSN_NODE_LOOP(node, N, WPN)                                              \
+#define VSN_NODE_LOOP_B(node, N, WPN, BID, NBLK)                                  \
   const int lane = threadIdx.x & 63;                                             \
   const int wv__ = uni((int)(threadIdx.x >> 6)); /* wave id: make it an SGPR */  \
   const int sub = (WPN) == 1 ? 0 : wv__;                                         \
   const int npb__ = (WPN) == 1 ? (int)(blockDim.x >> 6) : 1;                     \
-  const int blk__ = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;               \
-  for (int node = blk__ * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += gridDim.x * npb__)
+  const int nblk__ = (NBLK);                                                     \
+  const int blk__ = VSN_XCD_REMAP ? xcd_block((BID), nblk__) : (BID);            \
+  for (int node = blk__ * npb__ + ((WPN) == 1 ? wv__ : 0); node < (N); node += nblk__ * npb__)
+#define VSN_NODE_LOOP(node, N, WPN) VSN_NODE_LOOP_B(node, N, WPN, (int)blockIdx.x, (int)gridDim.x)
 
 // Edge-id cache: one coalesced load brings the ids of (up to) 64 consecutive edges of a node into the
 // wave's lanes; the edge loop then picks them with v_readlane instead of a dependent scalar load per edge

@@ -721,7 +721,10 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       RC(launch_edge_update(c->side, D, b.vp, b.pe, c->f));
       HIPCHK(c, hipEventRecord(c->ev_join, c->side));
     }
-    RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
+    // single-protein sizes: the edge update rides in the attention launch (horizontal fusion)
+    const bool fused_eu = c->fuse_fwd && !side_eu && !c->debug && !last && !l0 && N < 4096;
+    if (fused_eu) RC(launch_edge_attn_update(st, D, b.qkv, b.pe, c->m, c->A, b.vp, c->f));
+    else RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
     snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
     snapshot(c, st, "A", l, c->A, (size_t)N * H);
     {
@@ -745,7 +748,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec, nn));
     }
     if (side_eu) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
-    else if (!last && !l0) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
+    else if (!last && !l0 && !fused_eu) RC(launch_edge_update(st, D, b.vp, b.pe, c->f));
   }
   snapshot(c, st, "x_in", L, c->x, (size_t)N * H);
   snapshot(c, st, "vec_in", L, c->vec, (size_t)N * S * H);

@@ -130,6 +130,8 @@ int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int
                            const float* xn, const float* rstd, const float* gamma, const float* wvec,
                            int accumulate, float* g_x, float* g_vec, const float* vp, const float* o, float* g_o,
                            float* g_vp);
+int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A,
+                            const float* vp, float* f);
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f);
 
 // ---- reverse ----

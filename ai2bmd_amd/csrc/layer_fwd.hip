@@ -173,14 +173,12 @@ __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restri
 // ---- attention + scalar message + its aggregation (visnet_block.py:276-283,305) --
 // a_h = silu(sum_c q_i k_j dk) * C ; m_e = v_j * dv * a ; A_i = sum_e m_e
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D, const float* __restrict__ qkv,
-                                                                         const float* __restrict__ pe,
-                                                                         float* __restrict__ m,
-                                                                         float* __restrict__ A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __restrict__ qkv,
+                                               const float* __restrict__ pe, float* __restrict__ m,
+                                               float* __restrict__ A, float* __restrict__ smem, int bid, int nblk) {
   const int H = D.H;
   const int lph = 64 / D.nh;  // lanes per head
-  VSN_NODE_LOOP(i, D.N, WPN) {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], acc[1][V];
@@ -210,6 +208,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D,
     node_reduce<V, 1, WPN>(acc, smem, lane, sub);
     if (sub == 0) strow<V>(A + (size_t)i * H, lane, acc[0]);
   }
+}
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D, const float* __restrict__ qkv,
+                                                                         const float* __restrict__ pe,
+                                                                         float* __restrict__ m,
+                                                                         float* __restrict__ A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  edge_attn_body<V, S, WPN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- vector messages, their aggregation and the node update ---------------------
@@ -318,11 +324,11 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
 // ---- edge update (visnet_block.py:290-295): f_e += silu(pf_e) * <rej(wt_i,d), rej(ws_j,d)> ---
 // <w1,w2> = u1.u2 + (u1.d)(u2.d)(|d|^2 - 2)   (expanded double rejection)
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims D, const float* __restrict__ vp,
-                                                                           const float* __restrict__ pe,
-                                                                           float* __restrict__ f) {
+__device__ __forceinline__ void edge_update_body(const Dims& D, const float* __restrict__ vp,
+                                                 const float* __restrict__ pe, float* __restrict__ f, int bid,
+                                                 int nblk) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N, WPN) {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V];
@@ -355,6 +361,27 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims 
       strow<V>(f + (size_t)e * H, lane, fv);
     }
   }
+}
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims D, const float* __restrict__ vp,
+                                                                           const float* __restrict__ pe,
+                                                                           float* __restrict__ f) {
+  edge_update_body<V, S, WPN>(D, vp, pe, f, (int)blockIdx.x, (int)gridDim.x);
+}
+// Horizontal fusion of the two independent edge walks of a layer (both consume the edge linears `pe`):
+// blocks [0, G) do the attention, blocks [G, 2G) the edge update.  On a single protein both are latency-bound,
+// so one launch runs them side by side without the ~15 us event latency a second stream would cost.
+template <int V, int S, int WPN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(Dims D, const float* __restrict__ qkv,
+                                                                                const float* __restrict__ pe,
+                                                                                float* __restrict__ m,
+                                                                                float* __restrict__ A,
+                                                                                const float* __restrict__ vp,
+                                                                                float* __restrict__ f) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = (int)gridDim.x >> 1;
+  if ((int)blockIdx.x < G) edge_attn_body<V, S, WPN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, G);
+  else edge_update_body<V, S, WPN>(D, vp, pe, f, (int)blockIdx.x - G, G);
 }
 
 // ---- launchers -------------------------------------------------------------------
@@ -389,6 +416,15 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
 int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A) {
   if (D.N <= 0) return 0;
   VSN_LAUNCH(k_edge_attn, 1, D, qkv, pe, m, A);
+  return 0;
+}
+int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A,
+                            const float* vp, float* f) {
+  if (D.N <= 0) return 0;
+  const int w__ = pick_wpn(D.N);
+  VSN_DISPATCH_VS(D.H, D.S, w__, k_edge_attn_update,
+                  <<<2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st>>>(D, qkv, pe, m, A,
+                                                                                                   vp, f));
   return 0;
 }
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
