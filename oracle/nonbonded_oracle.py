@@ -3,8 +3,10 @@
   /root/reference/src/AIMD/protein.py:133-151          (all ordered pairs i != j minus exclude_pair)
   /root/reference/src/Fragmentation/distancefrag.py:355-363 (exclude_pair = pairs inside one dipeptide)
 
-PARITY UNPINNED against a run of the reference: its module imports `ase.units` and `AIMD.protein`
-(ase, openmm), neither installed here.  The unit constants are restated from ASE's CODATA-2014 table
+Pinned on a run of the reference's own `MMNonBondedCalculator` (oracle/make_nonbonded_golden.py ->
+tests/golden/mm_*.npz): the module is loaded from the reference tree with its two absent imports stubbed -
+`ase.units` (ASE is not installed; third-party, version unpinned by the reference) and the `Protein` type
+annotation.  The unit constants are restated from ASE's CODATA-2014 table
 (ase.units since 3.12): _e = 1.6021766208e-19 C, _Nav = 6.022140857e23, _eps0 = 1/(mu0 c^2) with
 mu0 = 4e-7 pi, c = 299792458 -> C = 1/_e, kJ = 1000/_e, mol = _Nav, nm = 10 Angstrom.
 The restatement is checked against its own finite-difference gradient and against a brute-force

@@ -99,3 +99,44 @@ def test_hip_kernel_matches_oracle(lib_built, name):
     pos = torch.as_tensor(prot.positions.astype(np.float32)).to("cuda:0")
     _, F2 = calc.forces_device(pos, f_out=base, accumulate=True)
     np.testing.assert_allclose(F2.cpu().numpy(), F + 1.0, rtol=0, atol=1e-5 * max(1.0, np.abs(F).max()))
+
+
+def _amber_params(prot):
+    from ai2bmd_amd.amber import load_tables, protein_mm_parameters
+
+    return protein_mm_parameters(prot, load_tables(os.path.join(GOLDEN, "amber_tables.npz")))
+
+
+@pytest.mark.parametrize("name", ["chig", "trpcage"])
+def test_oracle_matches_reference_calculator(name):
+    """golden = /root/reference/src/Calculators/nonbonded.py MMNonBondedCalculator run on the same protein
+    (oracle/make_nonbonded_golden.py), AMBER-table parameters."""
+    from ai2bmd_amd.fragmentation import build_plan
+    from oracle.nonbonded_oracle import exclude_pairs_from_dipeptides, mm_nonbonded, pair_list
+
+    prot = load_protein(name)
+    plan = build_plan(prot)
+    gold = np.load(os.path.join(GOLDEN, f"mm_{name}.npz"))
+    q, s, e = _amber_params(prot)
+    src, dst = pair_list(plan.n_prot, exclude_pairs_from_dipeptides(dipeptide_atom_lists(plan)))
+    assert len(src) == int(gold["n_pairs"])
+    E, F = mm_nonbonded(prot.positions, q.astype(np.float64), s.astype(np.float64), e.astype(np.float64), src, dst)
+    assert abs(E - float(gold["energy"])) <= 2e-5 * max(1.0, abs(E))            # the reference computes in fp32
+    assert np.abs(F - gold["forces"]).max() <= 2e-5 * np.abs(F).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["chig", "trpcage"])
+def test_hip_kernel_matches_reference_calculator(lib_built, name):
+    from ai2bmd_amd.fragmentation import build_plan
+    from ai2bmd_amd.nonbonded import MMNonBondedCalculator
+
+    prot = load_protein(name)
+    plan = build_plan(prot)
+    gold = np.load(os.path.join(GOLDEN, f"mm_{name}.npz"))
+    q, s, e = _amber_params(prot)
+    calc = MMNonBondedCalculator("cuda:0")
+    calc.set_parameters(SimpleNamespace(charges=q, sigmas=s, epsilons=e), plan)
+    E, F = calc(SimpleNamespace(positions=prot.positions))
+    assert abs(E - float(gold["energy"])) <= 5e-5 * max(1.0, abs(float(gold["energy"])))
+    assert np.abs(F - gold["forces"]).max() <= 1e-4 * np.abs(gold["forces"]).max()
