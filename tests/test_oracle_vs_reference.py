@@ -25,3 +25,98 @@ def test_live_reference(vn, lmax, mnb):
     assert np.diff(c["graph"]["rowptr"]).max() <= mnb
     np.testing.assert_allclose(E, E_ref, atol=1e-10)
     np.testing.assert_allclose(F, F_ref, atol=1e-10)
+
+
+def _load_reference_module(name, relpath, stubs=()):
+    """import one file of the reference tree by path, with the named absent imports stubbed"""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    shim_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims")
+    if shim_dir not in sys.path:
+        sys.path.insert(0, shim_dir)
+    for modname, attrs in stubs:
+        m = types.ModuleType(modname)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules.setdefault(modname, m)
+    spec = importlib.util.spec_from_file_location(name, os.path.join("/root/reference/src", relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_live_reference_combiner():
+    """ai2bmd_amd.bonded.combine_numpy / fragmentation.combine_host against the reference's own
+    DipeptideBondedCombiner (Calculators/combiner.py) on a real fragment plan."""
+    import os
+
+    from ai2bmd_amd.bonded import combine_numpy
+    from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, combine_host
+    from conftest import GOLDEN
+
+    ref = _load_reference_module("ref_combiner", "Calculators/combiner.py").DipeptideBondedCombiner
+    d = np.load(os.path.join(GOLDEN, "protein_trpcage.npz"))
+    plan = build_plan(ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"]))
+    rng = np.random.default_rng(3)
+    f_all = rng.standard_normal((len(plan.z), 3)).astype(np.float32)
+    e_all = rng.standard_normal(len(plan.start)).astype(np.float32)
+    rows_dip = plan.row_of_cat[:plan.n_dip_rows]
+    rows_ace = plan.row_of_cat[plan.n_dip_rows:]
+    f_dip, f_ace = f_all[rows_dip], f_all[rows_ace]
+    e_dip, e_ace = e_all[plan.is_dipeptide], e_all[~plan.is_dipeptide]
+    F_ref = ref.forces_combine(plan.n_prot, torch.as_tensor(f_dip), torch.as_tensor(f_ace),
+                               torch.as_tensor(plan.select_index), torch.as_tensor(plan.origin_index))
+    E_ref = float(ref.energy_combine(torch.as_tensor(e_dip), torch.as_tensor(e_ace)))
+    E1, F1 = combine_numpy(plan.n_prot, e_dip, f_dip, e_ace, f_ace, plan.select_index, plan.origin_index)
+    E2, F2 = combine_host(plan, e_all[:, None], f_all)
+    assert abs(float(E1) - E_ref) < 1e-5 and abs(float(E2) - E_ref) < 1e-5
+    np.testing.assert_allclose(F1, F_ref, atol=1e-6)
+    np.testing.assert_allclose(F2, F_ref, atol=1e-6)
+
+
+@pytest.mark.parametrize("ndev,chunk", [(1, 9999), (2, 9999), (4, 120), (8, 9999), (3, 70)])
+def test_live_reference_work_partitions(lib_built, ndev, chunk):
+    """vsn_partition (C) against the reference's own DeviceStrategy._set_combined_work_partitions."""
+    from ai2bmd_amd.device_strategy import work_partitions
+
+    mod = _load_reference_module(
+        "ref_device_strategy", "Calculators/device_strategy.py",
+        stubs=(("AIMD", {}), ("AIMD.fragment", {"FragmentInfo": object}), ("utils", {}),
+               ("utils.system", {"get_physical_core_count": lambda: 8})))
+    DS = mod.DeviceStrategy
+    rng = np.random.default_rng(ndev * 100 + chunk)
+    sizes = []
+    for _ in range(35):
+        sizes += [int(rng.integers(19, 37)), 12]
+    sizes.append(int(rng.integers(19, 37)))
+    end = np.cumsum(sizes)
+    start = end - np.asarray(sizes)
+    DS._chunk_size = chunk
+    DS._set_combined_work_partitions(list(range(ndev)), start.tolist(), end.tolist())
+    assert work_partitions(start, end, ndev, chunk) == [tuple(int(v) for v in t) for t in DS._work_partitions]
+
+
+def test_live_reference_fragment_data():
+    """ai2bmd_amd.fragment.FragmentData against the reference's own class (AIMD/fragment.py; `ase.Atoms` stubbed):
+    slicing re-bases start/end/batch the same way, scalar/vector splits agree, including an empty (CYZ) fragment."""
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+
+    Ref = _load_reference_module("ref_fragment", "AIMD/fragment.py", stubs=(("ase", {"Atoms": object}),)).FragmentData
+    sizes = [22, 12, 0, 12, 30, 12, 25]
+    end = np.cumsum(sizes)
+    start = end - np.asarray(sizes)
+    n = int(end[-1])
+    args = (np.arange(n), np.arange(3 * n, dtype=np.float32).reshape(n, 3), start, end, make_batch_index(start, end))
+    mine, ref = FragmentData(*args), Ref(*args)
+    for a, b in zip(mine.scalar_split(), ref.scalar_split()):
+        assert np.array_equal(a, b)
+    for a, b in zip(mine.vector_split(), ref.vector_split()):
+        assert np.array_equal(a, b)
+    for sl in (slice(0, 7), slice(1, 4), slice(3, 6), 4, 0):
+        m, r = mine[sl], ref[sl]
+        for k in ("z", "pos", "start", "end", "batch"):
+            assert np.array_equal(getattr(m, k), getattr(r, k)), (sl, k)
+        assert len(m) == len(r)
