@@ -110,3 +110,54 @@ def test_sharded_path_world2_gloo(tmp_path, lib_built):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def _row_permutation(plan, prot_pos, ref):
+    """row of OUR batch for every row of the reference's batch (AMBER order there, residue order here):
+    matched inside each fragment by (atomic number, position)."""
+    from ai2bmd_amd.fragmentation import fragment_positions
+
+    mine = fragment_positions(plan, prot_pos).astype(np.float32)
+    perm = -np.ones(len(ref["z"]), dtype=np.int64)
+    for b in range(len(plan.start)):
+        a0, a1 = int(plan.start[b]), int(plan.end[b])
+        assert (a0, a1) == (int(ref["start"][b]), int(ref["end"][b]))
+        used = set()
+        for r in range(a0, a1):
+            d = np.abs(mine[a0:a1] - ref["pos"][r]).max(axis=1)
+            d[plan.z[a0:a1] != ref["z"][r]] = np.inf
+            k = int(np.argmin(d))
+            assert d[k] < 2e-4 and k not in used, (b, r, d[k])
+            used.add(k)
+            perm[r] = a0 + k
+    return perm
+
+
+@pytest.mark.parametrize("name", ["chig"])
+def test_plan_matches_reference_fragmenter(name):
+    """golden = the reference's own DistanceFragment.fragment + get_dipeptide_positions (oracle/ref_fragmenter.py) on
+    its pre-processed Chignolin example: same fragments, same atoms, same cap-hydrogen first-guess positions, same
+    force recombination (the reference's rows are in AMBER order, ours in residue order: matched by position)."""
+    from ai2bmd_amd.fragmentation import build_plan, combine_host
+
+    prot = load_protein(name)
+    plan = build_plan(prot)
+    ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
+    assert np.array_equal(plan.start, ref["start"]) and np.array_equal(plan.end, ref["end"])
+    assert plan.n_dip_rows == int(ref["n_dip_rows"])
+    perm = _row_permutation(plan, prot.positions, ref)          # also proves: same atoms and positions per fragment
+    assert sorted(perm.tolist()) == list(range(len(plan.z)))
+    # forces: random per-row forces in the REFERENCE's row order, recombined by the reference's rule
+    # (combiner.py:24-41 with the reference's select/origin indices) == ours on the permuted rows
+    rng = np.random.default_rng(0)
+    f_ref = rng.standard_normal((len(ref["z"]), 3))
+    is_dip = np.zeros(len(ref["z"]), bool)
+    for b in range(0, len(ref["start"]), 2):
+        is_dip[ref["start"][b]:ref["end"][b]] = True
+    cat = np.concatenate([f_ref[is_dip], -f_ref[~is_dip]])[ref["select_index"]]
+    F_ref = np.zeros((plan.n_prot, 3))
+    np.add.at(F_ref, ref["origin_index"], cat)
+    f_mine = np.zeros_like(f_ref)
+    f_mine[perm] = f_ref
+    _, F_mine = combine_host(plan, np.zeros((len(plan.start), 1), np.float32), f_mine.astype(np.float32))
+    np.testing.assert_allclose(F_mine, F_ref, atol=1e-5)

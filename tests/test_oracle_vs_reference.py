@@ -120,3 +120,18 @@ def test_live_reference_fragment_data():
         for k in ("z", "pos", "start", "end", "batch"):
             assert np.array_equal(getattr(m, k), getattr(r, k)), (sl, k)
         assert len(m) == len(r)
+
+
+def test_live_reference_fragmenter_matches_golden():
+    """the committed golden of the reference's fragmenter is what the reference tree produces now"""
+    import os
+
+    from ai2bmd_amd.fragmentation import ProteinAtoms
+    from conftest import GOLDEN
+    from oracle.ref_fragmenter import run_reference_fragmenter
+
+    d = np.load(os.path.join(GOLDEN, "protein_chig.npz"))
+    r = run_reference_fragmenter(ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"]))
+    g = np.load(os.path.join(GOLDEN, "fragref_chig.npz"))
+    assert np.array_equal(r["z"], g["z"]) and np.array_equal(r["select_index"], g["select_index"])
+    assert np.array_equal(r["origin_index"], g["origin_index"]) and np.allclose(r["pos"], g["pos"], atol=1e-6)
