@@ -135,3 +135,31 @@ def test_live_reference_fragmenter_matches_golden():
     g = np.load(os.path.join(GOLDEN, "fragref_chig.npz"))
     assert np.array_equal(r["z"], g["z"]) and np.array_equal(r["select_index"], g["select_index"])
     assert np.array_equal(r["origin_index"], g["origin_index"]) and np.allclose(r["pos"], g["pos"], atol=1e-6)
+
+
+def test_live_reference_load_model_reads_our_checkpoint(tmp_path):
+    """the Lightning-shaped file written by ai2bmd_amd.synthetic.write_lightning_ckpt (what ViSNetModel.from_file
+    reads) goes through the reference's own `load_model` (ViSNet/model/visnet.py:73-93) and evaluates to the oracle."""
+    from ai2bmd_amd.synthetic import write_lightning_ckpt
+    from oracle.ref_import import import_reference_create_model
+
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    sd = make_state_dict(hp, seed=9)
+    path = str(tmp_path / "visnet.ckpt")
+    write_lightning_ckpt(path, hp, sd)
+    import_reference_create_model()
+    import ViSNet.model.visnet as visnet  # the reference's module (through oracle/shims)
+
+    real_script = torch.jit.script
+    torch.jit.script = lambda m, *a, **k: m  # the PyG stand-in is plain Python; TorchScript is not part of the format
+    try:
+        model = visnet.load_model(path, device="cpu")
+    finally:
+        torch.jit.script = real_script
+    z, pos, start, end = random_fragments(77, [22, 12, 30])
+    batch = np.repeat(np.arange(len(start)), end - start)
+    E_ref, F_ref = model(dict(z=torch.as_tensor(z), pos=torch.as_tensor(pos, dtype=torch.float32),
+                              batch=torch.as_tensor(batch)))
+    E, F, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    np.testing.assert_allclose(E_ref.detach().numpy(), E, atol=2e-4)
+    np.testing.assert_allclose(F_ref.detach().numpy(), F, atol=2e-4)
