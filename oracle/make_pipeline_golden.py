@@ -1,0 +1,142 @@
+"""TEST INFRASTRUCTURE / DATA PREP - the reference's whole bonded path for one MD step of Chignolin, run from the
+reference's OWN code in the build container, as an end-to-end golden vector:
+
+  DistanceFragment.fragment(prot)                                  (Fragmentation/distancefrag.py:94-363)
+  DistanceFragment.get_fragments(prot): cap-hydrogen placement + HydrogenOptimizer.optimize_hydrogen
+                                                                   (distancefrag.py:56-92, hydrogen/energies.py)
+  ViSNet forward + forces on the FragmentData                      (ViSNet/model/*.py through oracle/shims)
+  FragmentData.scalar_split / vector_split                         (AIMD/fragment.py:31-47)
+  DipeptideBondedCombiner.energy_combine / forces_combine          (Calculators/combiner.py)
+i.e. what DLBondedCalculator.__call__ does (Calculators/bonded.py:104-123) minus its thread pool.
+
+    python -m oracle.make_pipeline_golden      (build container only)
+
+Restated glue (torch_geometric is absent): the batching of the per-dipeptide `ProteinData` into one batch
+(hydrogen/topology.py:109-130 `__inc__`: atom indices += natom, parameter indices += numbnd / numang / nptra /
+ntypes(ntypes+1)/2) - the per-dipeptide term lists themselves come from the reference's `CTable` on the reference's
+own `constrain_index`.  Weights: seeded random (ai2bmd_amd/synthetic.py), small model (H=128, L=3).
+"""
+import os
+import sys
+import types
+
+os.environ["PYTORCH_JIT"] = "0"
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from ai2bmd_amd.fragmentation import ProteinAtoms  # noqa: E402
+from ai2bmd_amd.synthetic import default_hparams, make_state_dict  # noqa: E402
+from oracle import ref_fragmenter  # noqa: E402
+from oracle.make_golden import run_reference  # noqa: E402
+from oracle.make_hydrogen_golden import reference_modules  # noqa: E402
+
+HP_OVER = dict(embedding_dimension=128, num_layers=3)
+WEIGHT_SEED = 21
+
+
+def reference_hydrogen_batch(CTable, resi_info, lengths, constrain_index, fragment_info):
+    """what create_protein_graph + ProteinDataBatch.from_data_list build (distancefrag.py:847-894, topology.py)"""
+    keys = ("atom_idx", "other_idx", "charge", "bond_force_constant", "bond_equil_value", "angle_force_constant",
+            "angle_equil_value", "dihedral_force_constant", "dihedral_periodicity", "dihedral_phase",
+            "lennard_jones_acoef", "lennard_jones_bcoef", "bonds_atom_idx_src", "bonds_atom_idx_dst", "bond_idx",
+            "angles_atom_idx_i", "angles_atom_idx_j", "angles_atom_idx_k", "angle_idx", "dihedrals_atom_idx_i",
+            "dihedrals_atom_idx_j", "dihedrals_atom_idx_k", "dihedrals_atom_idx_l", "dihedral_idx",
+            "nonbonded_atom_idx_src", "nonbonded_atom_idx_dst", "lj_idx", "bond_batch", "angle_batch",
+            "dihedral_batch", "nonbonded_batch")
+    cat = {k: [] for k in keys}
+    off = dict(atom=0, bnd=0, ang=0, dih=0, lj=0)
+    ctables, g = {}, 0
+    for info, length, constrain_idx in zip(resi_info, lengths, constrain_index):
+        if not length:
+            continue
+        code = fragment_info[info[0]][0]
+        if code not in ctables:
+            ctables[code] = CTable.from_prmtop(f"/root/reference/src/Fragmentation/prmtop/{code}.prmtop")
+        ct = ctables[code]
+        atom_idx = torch.tensor(constrain_idx, dtype=torch.long)
+        mask = torch.zeros(length, dtype=torch.bool)
+        mask[atom_idx] = True
+        other_idx = torch.arange(length)[~mask]
+        cat["atom_idx"].append(atom_idx + off["atom"])
+        cat["other_idx"].append(other_idx + off["atom"])
+        for k in keys[2:12]:
+            cat[k].append(getattr(ct, k).float())
+        bs, bd, bi = ct.filter_bonds(atom_idx)
+        ai, aj, ak, aidx = ct.filter_angles(atom_idx)
+        di, dj, dk, dl, didx = ct.filter_dihedrals(atom_idx)
+        ns, nd = ct.gen_nonbonded_pair(atom_idx)
+        lj = ct.generate_lj_idx(ns, nd)
+        for k, v in (("bonds_atom_idx_src", bs), ("bonds_atom_idx_dst", bd), ("angles_atom_idx_i", ai),
+                     ("angles_atom_idx_j", aj), ("angles_atom_idx_k", ak), ("dihedrals_atom_idx_i", di),
+                     ("dihedrals_atom_idx_j", dj), ("dihedrals_atom_idx_k", dk), ("dihedrals_atom_idx_l", dl),
+                     ("nonbonded_atom_idx_src", ns), ("nonbonded_atom_idx_dst", nd)):
+            cat[k].append(v + off["atom"])
+        cat["bond_idx"].append(bi + off["bnd"])
+        cat["angle_idx"].append(aidx + off["ang"])
+        cat["dihedral_idx"].append(didx + off["dih"])
+        cat["lj_idx"].append(lj + off["lj"])
+        for k, ref in (("bond_batch", bi), ("angle_batch", aidx), ("dihedral_batch", didx), ("nonbonded_batch", lj)):
+            cat[k].append(torch.full_like(ref, g))
+        off["atom"] += ct.natom
+        off["bnd"] += ct.numbnd
+        off["ang"] += ct.numang
+        off["dih"] += ct.nptra
+        off["lj"] += ct.ntypes * (ct.ntypes + 1) // 2
+        g += 1
+    return types.SimpleNamespace(pos=None, **{k: torch.cat(v) for k, v in cat.items()})
+
+
+def main():
+    CTable, HydrogenOptimizer = reference_modules()        # reference ctable.py / energies.py
+    DF = ref_fragmenter.load_distance_fragment()           # reference basefrag.py / distancefrag.py
+    fragment_info = sys.modules["utils.reference"].fragment_info
+    captured = {}
+    DF.create_protein_graph = staticmethod(
+        lambda resi_info, lengths, constrain: captured.update(resi_info=resi_info, lengths=lengths, constrain=constrain) or [])
+    frag = DF()
+    frag.optimizer = HydrogenOptimizer(10)                 # distancefrag.py:30-32
+    z = np.load(os.path.join(ROOT, "tests", "golden", "protein_chig.npz"))
+    rng = np.random.default_rng(17)
+    prot_pos = z["positions"] + 0.03 * rng.standard_normal(z["positions"].shape)  # a thermally displaced frame
+    p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
+                     positions=prot_pos)
+    prot = ref_fragmenter.DuckProtein(p)
+    frag.fragment(prot)
+    frag.batch = reference_hydrogen_batch(CTable, captured["resi_info"], captured["lengths"], captured["constrain"],
+                                          fragment_info)
+    fd = frag.get_fragments(prot)                          # reference FragmentData, relaxed cap hydrogens
+    hp = default_hparams(**HP_OVER)
+    sd = make_state_dict(hp, seed=WEIGHT_SEED)
+    e32, f32 = run_reference(hp, sd, fd.z, fd.pos, fd.start, fd.end, torch.float32)
+    e64, f64 = run_reference(hp, sd, fd.z, fd.pos.astype(np.float64), fd.start, fd.end, torch.float64)
+    out = {}
+    for tag, e, f in (("32", e32, f32), ("64", e64, f64)):
+        e_t, f_t = torch.as_tensor(e).reshape(-1), torch.as_tensor(f)
+        e_dip, e_ace = (e_t[s] for s in fd.scalar_split())
+        f_dip, f_ace = (f_t[s] for s in fd.vector_split())
+        comb = sys.modules["Calculators.combiner"].DipeptideBondedCombiner if "Calculators.combiner" in sys.modules else None
+        if comb is None:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("Calculators.combiner", "/root/reference/src/Calculators/combiner.py")
+            mod = importlib.util.module_from_spec(spec)
+            sys.path.insert(0, os.path.join(HERE, "shims"))
+            spec.loader.exec_module(mod)
+            sys.modules["Calculators.combiner"] = mod
+            comb = mod.DipeptideBondedCombiner
+        out[f"E{tag}"] = np.float64(comb.energy_combine(e_dip, e_ace))
+        out[f"F{tag}"] = comb.forces_combine(len(prot), f_dip, f_ace, prot.select_index, prot.origin_index).astype(np.float64)
+    print(f"chig: B={len(fd.start)} N={len(fd.z)}  E32 {out['E32']:.6f} E64 {out['E64']:.6f}  "
+          f"max|F32-F64| {np.abs(out['F32'] - out['F64']).max():.2e}  max|F| {np.abs(out['F64']).max():.3f}")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pipeline_chig.npz"), prot_pos=prot_pos,
+                        frag_pos=fd.pos.astype(np.float32), frag_z=np.asarray(fd.z).astype(np.int16),
+                        weight_seed=WEIGHT_SEED, E32=out["E32"], E64=out["E64"], F32=out["F32"].astype(np.float32),
+                        F64=out["F64"])
+
+
+if __name__ == "__main__":
+    main()
