@@ -100,6 +100,109 @@ __global__ __launch_bounds__(64 * WPB) void k_wave(const float* __restrict__ A, 
     }
 }
 
+
+// general workgroup tile: BM x BN per workgroup of WM x WN waves, each wave (BM/WM) x (BN/WN), double-buffered LDS,
+// one barrier per k-tile (the production scheme with a free number of waves)
+template <int BM, int BN, int WM, int WN, bool DB>
+__global__ __launch_bounds__(64 * WM * WN) void k_wgt(const float* __restrict__ A, const float* __restrict__ Bt,
+                                                      float* __restrict__ C, const float* __restrict__ bias, int M,
+                                                      int Nc, int K) {
+  constexpr int NT = 64 * WM * WN, BK = 32, LS = 36, STAGE = (BM + BN) * LS;
+  constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+  constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;
+  static_assert(LA >= 1 && LB >= 1, "tile too small for this many threads");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int tiles_n = Nc / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n, row0 = tm * BM, col0 = tn * BN;
+  f32x4 ra[LA], rb[LB];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < LA; ++it) {
+      const int f = tid + it * NT, r = f >> 3, c4 = f & 7;
+      int gr = row0 + r;
+      gr = gr < M ? gr : M - 1;
+      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr * K + k0 + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < LB; ++it) {
+      const int f = tid + it * NT, r = f >> 3, c4 = f & 7;
+      rb[it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r) * K + k0 + c4 * 4);
+    }
+  };
+  auto sstore = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LS;
+#pragma unroll
+    for (int it = 0; it < LA; ++it) {
+      const int f = tid + it * NT, r = f >> 3, c4 = f & 7;
+      *reinterpret_cast<f32x4*>(As + r * LS + c4 * 4) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < LB; ++it) {
+      const int f = tid + it * NT, r = f >> 3, c4 = f & 7;
+      *reinterpret_cast<f32x4*>(Bs + r * LS + c4 * 4) = rb[it];
+    }
+  };
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nkt = K / BK;
+  gload(0);
+  if (DB) {
+    sstore(0);
+    gload((1 < nkt ? 1 : 0) * BK);
+    __syncthreads();
+  }
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (!DB) {
+      sstore(0);
+      __syncthreads();
+      gload((kt + 1 < nkt ? kt + 1 : kt) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float* As = smem + (DB ? (kt & 1) : 0) * STAGE;
+    const float* Bs = As + BM * LS;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[MI], b[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + (wm * TM + i * 32 + l31) * LS + kk * 8 + hi * 4);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * TN + j * 32 + l31) * LS + kk * 8 + hi * 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    }
+    if (DB && kt + 1 < nkt) {
+      sstore((kt + 1) & 1);
+      gload((kt + 2 < nkt ? kt + 2 : kt + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = col0 + wn * TN + j * 32 + l31;
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (row < M) C[(size_t)row * Nc + col] = acc[i][j][r] + bv;
+      }
+    }
+}
+
 // production-shaped reference point: 64x64 tile, 4 waves (2x2), double-buffered LDS, one barrier per k-tile
 __global__ __launch_bounds__(256) void k_wg64(const float* __restrict__ A, const float* __restrict__ Bt,
                                               float* __restrict__ C, const float* __restrict__ bias, int M, int Nc,
@@ -239,6 +342,31 @@ int main() {
       hipMemset(C, 0, nc * 4);
       report("wg64 4 waves barrier", time_us([&] { hipLaunchKernelGGL(k_wg64, dim3(grid), dim3(256), 0, 0, A, B, C, bias, s.M, s.Nc, s.K); }));
     }
+
+#define RUN_WGT(BM, BN, WM, WN, DB)                                                                                  \
+  if (s.Nc % BN == 0) {                                                                                              \
+    const int grid = ((s.M + BM - 1) / BM) * (s.Nc / BN);                                                            \
+    const size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * 36 * 4;                                                    \
+    hipFuncSetAttribute((const void*)k_wgt<BM, BN, WM, WN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipMemset(C, 0, nc * 4);                                                                                         \
+    report("wgt " #BM "x" #BN " w" #WM "x" #WN " db" #DB, time_us([&] {                                              \
+             hipLaunchKernelGGL((k_wgt<BM, BN, WM, WN, DB>), dim3(grid), dim3(64 * WM * WN), lds, 0, A, B, C, bias, s.M, s.Nc, s.K); \
+           }));                                                                                                      \
+  }
+    if (getenv("LAB_WGT")) {
+      RUN_WGT(64, 64, 2, 2, true)
+      RUN_WGT(64, 64, 2, 1, true)
+      RUN_WGT(64, 64, 1, 2, true)
+      RUN_WGT(64, 64, 1, 1, true)
+      RUN_WGT(128, 64, 4, 2, true)
+      RUN_WGT(128, 64, 4, 1, true)
+      RUN_WGT(128, 128, 4, 2, true)
+      RUN_WGT(128, 128, 4, 2, false)
+      RUN_WGT(128, 128, 4, 4, false)
+      RUN_WGT(128, 128, 2, 2, false)
+      RUN_WGT(64, 128, 2, 2, true)
+      RUN_WGT(64, 128, 2, 4, true)
+    } else {
 #define RUN_WAVE(TM, TN, WPB)                                                                                     \
   {                                                                                                               \
     const int tiles = ((s.M + TM - 1) / TM) * (s.Nc / TN);                                                        \
@@ -255,6 +383,7 @@ int main() {
     RUN_WAVE(64, 64, 1)
     RUN_WAVE(64, 32, 4)
     RUN_WAVE(32, 32, 4)
+    }
     hipFree(A);
     hipFree(B);
     hipFree(C);
