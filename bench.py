@@ -100,8 +100,11 @@ def main():
                     help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
     ap.add_argument("--no-relax-caps", action="store_true",
                     help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
-    ap.add_argument("--no-mm", action="store_true",
-                    help="skip the MM non-bonded term (reference: MMNonBondedCalculator added to the fragment forces)")
+    ap.add_argument("--mm", action="store_true",
+                    help="add the MM non-bonded term (reference: MMNonBondedCalculator on top of the fragment forces; "
+                         "< 1 %% of the step).  Off by default: with seeded random ViSNet weights nothing but the "
+                         "tether holds polar hydrogens (AMBER gives them no LJ core), so over thousands of steps the "
+                         "Coulomb term tears the structure apart and the workload would change under the clock")
     ap.add_argument("--emulate-shard", default="", help="tuning aid, single process: 'r/w' = time rank r's share of a "
                     "w-rank MD job without the collective (not a valid bench line)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
@@ -164,7 +167,7 @@ def main():
         else:
             ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
         force_fn = ff.step
-        if not args.no_mm:
+        if args.mm:
             # full AI2BMD potential = fragment (ViSNet) forces + MM Lennard-Jones/Coulomb between atoms that never
             # share a dipeptide (Calculators/nonbonded.py:33-63); charges / sigma / epsilon from the AMBER tables
             from types import SimpleNamespace
@@ -204,7 +207,7 @@ def main():
         n_loc = ff.local_rows
         workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
                     f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
-                    f"{'+ MM non-bonded (LJ + Coulomb, AMBER parameters), ' if not args.no_mm else ''}Langevin 1 fs 300 K "
+                    f"{'+ MM non-bonded (LJ + Coulomb, AMBER parameters), ' if args.mm else ''}Langevin 1 fs 300 K "
                     f"friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
                     f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
         scaling = "strong"
