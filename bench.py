@@ -189,12 +189,16 @@ def main():
         md = Integ(prot.numbers, prot.positions, force_fn, dev, seed=0, tether_k=5.0)
         for _ in range(args.warmup):
             md.step()
+        edges_before = eng.last_num_edges()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             md.step()
         barrier()
         el = time.perf_counter() - t0
+        edges_after = eng.last_num_edges()
+        # the workload must not change under the clock (a structure that flies apart has fewer edges = less work)
+        assert abs(edges_after - edges_before) <= 0.1 * max(edges_before, 1), (edges_before, edges_after)
         if world > 1:
             import torch.distributed as dist
 
@@ -221,7 +225,7 @@ def main():
         prof = eng.profile_read()
         eng.set_option("profile", 0)
         flops_eval = 2.0 * fwd_flops(n_loc, E_edges, H, L, S, R)
-        extra = dict(edges_local=E_edges, frag_atoms_local=n_loc, algorithmic_gflop_per_step_local=flops_eval / 1e9)
+        extra = dict(edges_local=E_edges, edges_at_start_of_timed_region=edges_before, frag_atoms_local=n_loc, algorithmic_gflop_per_step_local=flops_eval / 1e9)
         if world == 1:
             # the reference-shaped seam (host numpy in, host numpy out => H2D + D2H over PCIe every call);
             # reported for information, never as `value`
