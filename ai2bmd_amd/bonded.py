@@ -109,6 +109,7 @@ class ShardedFragmentForces:
         self.local_fn = self.combine_fn = None
         self.direct = False  # True when local_fn writes straight into the exchange buffer
         self.emulate = False
+        self.force_collective = False  # world == 1: still go through the all-gather (exercises RCCL on a 1-GPU box)
         self.energy_sign = torch.as_tensor(plan.energy_sign, device=device)
         nonempty = (plan.end - plan.start) > 0
         self._e_index = torch.as_tensor(
@@ -127,7 +128,7 @@ class ShardedFragmentForces:
     def step(self, prot_pos):
         """prot_pos [n_prot,3] on self.device -> (E 0-d tensor, F [n_prot,3] tensor)."""
         e_loc, f_loc = self.local_fn(prot_pos)
-        stage = self.recv if self.world == 1 else self.send
+        stage = self.recv if (self.world == 1 and not self.force_collective) else self.send
         if not self.direct:  # local_fn returned its own tensors: stage them into the exchange buffer
             stage[: self.local_rows * 3] = f_loc.reshape(-1)
             stage[self.max_rows * 3: self.max_rows * 3 + len(self.local_start)] = e_loc
@@ -135,7 +136,7 @@ class ShardedFragmentForces:
             # single-process stand-in for one rank of a `world`-rank job (tuning aid: per-rank step time at that
             # shard size on a 1-GPU box); the other ranks' slots stay zero
             self.recv[self.rank * self.slot:(self.rank + 1) * self.slot] = self.send
-        elif self.world > 1:
+        elif self.world > 1 or self.force_collective:
             import torch.distributed as dist
 
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
@@ -146,12 +147,14 @@ class ShardedFragmentForces:
 
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
-    def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None):
+    def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None,
+                   force_collective=False):
         """hydrogen: optional ai2bmd_amd.hydrogen.HydrogenPlan - relax the cap hydrogens every call like
         DistanceFragment.get_fragments (distancefrag.py:76-82).  The relaxation couples all dipeptides, so with
         it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard."""
         dev = engine.device
         self = cls(plan, rank, world, dev, group)
+        self.force_collective = bool(force_collective)
         L = capi.lib()
         lo, hi = self.atom_lo[rank], self.atom_hi[rank]
         # fragment geometry plan restricted to this rank's rows (all rows when the caps are relaxed)
@@ -187,7 +190,7 @@ class ShardedFragmentForces:
         self.frag_pos = pos_geo
         nloc, bloc = hi - lo, self.f1 - self.f0
         # the kernels write this rank's forces / energies straight into its slot of the exchange buffer
-        stage = self.recv if world == 1 else self.send
+        stage = self.recv if (world == 1 and not force_collective) else self.send
         f_loc = stage[: max(nloc, 1) * 3].view(-1, 3)
         e_loc = stage[self.max_rows * 3: self.max_rows * 3 + max(bloc, 1)]
         self.direct = True

@@ -115,3 +115,30 @@ def test_two_handles_driven_from_two_threads(setup):
         res = two.calculate(fd)
         for a, b in zip(one, res):
             np.testing.assert_allclose(b, a, rtol=0, atol=1e-5)
+
+
+def test_rccl_all_gather_path_on_one_gpu(setup):
+    """world_size-1 RCCL process group: the sharded evaluator goes through dist.all_gather_into_tensor on the GPU
+    (same code path as N > 1, exercised here because the round's GPU box has one device)."""
+    import torch.distributed as dist
+
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+
+    hp, sd, prot, plan, model = setup
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        x = torch.as_tensor(prot.positions, dtype=torch.float32, device="cuda:0")
+        E0, F0 = ShardedFragmentForces.for_engine(model.engine, plan).step(x)
+        F0 = F0.clone()
+        ff = ShardedFragmentForces.for_engine(model.engine, plan, force_collective=True)
+        E1, F1 = ff.step(x)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert float(E0) == float(E1) and torch.equal(F0, F1)
+    finally:
+        if created:
+            dist.destroy_process_group()
