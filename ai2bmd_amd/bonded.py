@@ -106,7 +106,7 @@ class ShardedFragmentForces:
         self.frag_owner, self.frag_local = frag_owner, frag_local
         self.send = torch.zeros(self.slot, dtype=torch.float32, device=device)
         self.recv = torch.zeros(world * self.slot, dtype=torch.float32, device=device)
-        self.local_fn = self.combine_fn = None
+        self.local_fn = self.combine_fn = self.combine_energy_fn = None
         self.direct = False  # True when local_fn writes straight into the exchange buffer
         self.emulate = False
         self.force_collective = False  # world == 1: still go through the all-gather (exercises RCCL on a 1-GPU box)
@@ -141,6 +141,8 @@ class ShardedFragmentForces:
 
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
         buf = self.recv
+        if self.combine_energy_fn is not None:  # product wiring: forces and total energy in one HIP launch
+            return self.combine_energy_fn(buf)
         F = self.combine_fn(buf)
         E = (buf[self._e_index] * self._e_sign).sum()
         return E, F
@@ -217,6 +219,22 @@ class ShardedFragmentForces:
                 raise RuntimeError(f"vsn_combine failed ({rc_})")
             return F_prot
 
-        self.local_fn, self.combine_fn = local_fn, combine_fn
-        self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot)
+        e_idx = np.ascontiguousarray(self._e_index.cpu().numpy(), dtype=np.int64)
+        e_sgn = np.ascontiguousarray(self._e_sign.cpu().numpy(), dtype=np.float32)
+        rc = L.vsn_combine_plan_set_energy(self._cp, len(e_idx), capi.i64_ptr(e_idx),
+                                           e_sgn.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc:
+            raise RuntimeError(f"vsn_combine_plan_set_energy failed ({rc})")
+        E_tot = torch.zeros(1, dtype=torch.float32, device=dev)
+
+        def combine_energy_fn(buf):
+            st = torch.cuda.current_stream(dev)
+            rc_ = L.vsn_combine_with_energy(self._cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
+                                            C.c_void_p(E_tot.data_ptr()), C.c_void_p(st.cuda_stream))
+            if rc_:
+                raise RuntimeError(f"vsn_combine_with_energy failed ({rc_})")
+            return E_tot[0], F_prot
+
+        self.local_fn, self.combine_fn, self.combine_energy_fn = local_fn, combine_fn, combine_energy_fn
+        self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot, E_tot)
         return self

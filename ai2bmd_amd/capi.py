@@ -95,6 +95,10 @@ def lib() -> C.CDLL:
     L.vsn_combine_plan_destroy.restype = None
     L.vsn_combine.argtypes = [vp, f32p, f32p, vp]
     L.vsn_combine.restype = C.c_int
+    L.vsn_combine_plan_set_energy.argtypes = [vp, C.c_int64, i64p, C.POINTER(C.c_float)]
+    L.vsn_combine_plan_set_energy.restype = C.c_int
+    L.vsn_combine_with_energy.argtypes = [vp, f32p, f32p, f32p, vp]
+    L.vsn_combine_with_energy.restype = C.c_int
     L.vsn_fragplan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int64, i64p, i64p, i64p, C.POINTER(C.c_float)]
     L.vsn_fragplan_create.restype = C.c_int
     L.vsn_fragplan_destroy.argtypes = [vp]
@@ -139,7 +143,7 @@ def i64_ptr(a):
 EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
     "vsn_forces", "vsn_profile_read", "vsn_last_num_edges", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
-    "vsn_combine_plan_destroy", "vsn_combine", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
+    "vsn_combine_plan_destroy", "vsn_combine", "vsn_combine_plan_set_energy", "vsn_combine_with_energy", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
     "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
     "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",
 ]

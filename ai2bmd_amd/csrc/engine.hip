@@ -1061,6 +1061,9 @@ struct vsn_combine_plan {
   int* off = nullptr;
   int* rows = nullptr;
   float* sign = nullptr;
+  int n_e = 0;
+  int* e_idx = nullptr;
+  float* e_sign = nullptr;
 };
 
 extern "C" int vsn_combine_plan_create(vsn_combine_handle* out, int device_id, int64_t n_prot, int64_t n_cat,
@@ -1105,7 +1108,42 @@ extern "C" void vsn_combine_plan_destroy(vsn_combine_handle p) {
   hipFree(p->off);
   hipFree(p->rows);
   hipFree(p->sign);
+  hipFree(p->e_idx);
+  hipFree(p->e_sign);
   delete p;
+}
+
+extern "C" int vsn_combine_plan_set_energy(vsn_combine_handle p, int64_t n, const int64_t* host_index,
+                                           const float* host_sign) {
+  if (!p || n < 0 || (n > 0 && (!host_index || !host_sign))) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  hipFree(p->e_idx);
+  hipFree(p->e_sign);
+  p->e_idx = nullptr;
+  p->e_sign = nullptr;
+  p->n_e = 0;
+  if (n == 0) return 0;
+  std::vector<int> idx((size_t)n);
+  for (int64_t k = 0; k < n; ++k) {
+    if (host_index[k] < 0 || host_index[k] > 0x7fffffff) return -22;
+    idx[(size_t)k] = (int)host_index[k];
+  }
+  if (hipMalloc((void**)&p->e_idx, (size_t)n * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&p->e_sign, (size_t)n * sizeof(float)) != hipSuccess)
+    return -12;
+  hipMemcpy(p->e_idx, idx.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice);
+  hipMemcpy(p->e_sign, host_sign, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+  p->n_e = (int)n;
+  return 0;
+}
+
+extern "C" int vsn_combine_with_energy(vsn_combine_handle p, const float* dev_buf, float* dev_f_prot,
+                                       float* dev_e_out, void* stream) {
+  if (!p || !dev_e_out || p->n_e <= 0) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  launch_combine((hipStream_t)stream, p->n_prot, p->off, p->rows, p->sign, dev_buf, dev_f_prot, p->n_e, p->e_idx,
+                 p->e_sign, dev_e_out);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
 extern "C" int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float* dev_f_prot, void* stream) {

@@ -163,9 +163,17 @@ int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const He
 
 // ---- overlap-force recombination (Calculators/combiner.py:38-39) ----------------
 // f_prot[a] = sum_{k in [off[a], off[a+1])} sign[k] * f_frag[rows[k]]   (fixed order)
+// optionally also E = sum_k e_sign[k] * buf[e_idx[k]] (combiner.py:19), reduced by the first wave in a fixed order
 __global__ void k_combine(int n_prot, const int* __restrict__ off, const int* __restrict__ rows,
                           const float* __restrict__ sign, const float* __restrict__ f_frag,
-                          float* __restrict__ f_prot) {
+                          float* __restrict__ f_prot, int n_e, const int* __restrict__ e_idx,
+                          const float* __restrict__ e_sign, float* __restrict__ e_out) {
+  if (e_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < n_e; k += 64) s += e_sign[k] * f_frag[e_idx[k]];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *e_out = s;
+  }
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_prot) return;
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -182,9 +190,10 @@ __global__ void k_combine(int n_prot, const int* __restrict__ off, const int* __
 }
 
 int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
-                   const float* f_frag, float* f_prot) {
+                   const float* f_frag, float* f_prot, int n_e, const int* e_idx, const float* e_sign, float* e_out) {
   if (n_prot <= 0) return 0;
-  hipLaunchKernelGGL(k_combine, dim3(nblk(n_prot)), dim3(256), 0, st, n_prot, off, rows, sign, f_frag, f_prot);
+  hipLaunchKernelGGL(k_combine, dim3(nblk(n_prot)), dim3(256), 0, st, n_prot, off, rows, sign, f_frag, f_prot, n_e,
+                     e_idx, e_sign, e_out);
   return 0;
 }
 

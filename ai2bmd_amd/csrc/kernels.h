@@ -182,7 +182,8 @@ int launch_vecnorm_bwd(hipStream_t st, int N, int H, int S, int norm_type, const
 
 // ---- combine (Calculators/combiner.py:24-41) ----
 int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
-                   const float* f_frag, float* f_prot);
+                   const float* f_frag, float* f_prot, int n_e = 0, const int* e_idx = nullptr,
+                   const float* e_sign = nullptr, float* e_out = nullptr);
 
 int launch_build_fragments(hipStream_t st, int n, const int* src, const int* acc, const int* tow, const float* len,
                            const float* prot, float* out);

@@ -119,6 +119,12 @@ void vsn_combine_plan_destroy(vsn_combine_handle p);
 /* dev_f_frag f32 [n_cat,3] (interleaved order) -> dev_f_prot f32 [n_prot,3];
  * dev_e_frag f32 [B] with host-provided sign per fragment folded into plan. */
 int vsn_combine(vsn_combine_handle p, const float* dev_f_frag, float* dev_f_prot, void* stream);
+/* total energy in the same launch (DipeptideBondedCombiner.energy_combine, combiner.py:12-22):
+ * E = sum_k host_sign[k] * dev_buf[host_index[k]] over the n per-fragment energies (float offsets into the buffer
+ * that also holds the forces; +1 dipeptide, -1 ACE-NME), summed in a fixed order -> dev_e_out f32 [1]. */
+int vsn_combine_plan_set_energy(vsn_combine_handle p, int64_t n, const int64_t* host_index, const float* host_sign);
+int vsn_combine_with_energy(vsn_combine_handle p, const float* dev_buf, float* dev_f_prot, float* dev_e_out,
+                            void* stream);
 
 /* ---- per-step fragment geometry (Fragmentation/distancefrag.py:35-54 + fragments_index gather) ----
  * Row k of the fragment batch is either a copy of protein atom host_src[k] (>= 0) or, when
