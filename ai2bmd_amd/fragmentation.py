@@ -14,15 +14,16 @@ Restates the behaviour of the reference's fragmenter
         acceptor -> removed-neighbour line),
   /root/reference/src/Fragmentation/distancefrag.py:250-350 (interleaving,
         select/origin indices for the force recombination)
-with two documented differences:
-  * atoms inside a fragment are ordered [previous-residue part | residue | next-
-    residue part] instead of AMBER's order (the reference permutes with
-    utils/seq_dict.pkl because its hydrogen optimiser needs AMBER topologies;
-    ViSNet is permutation-equivariant, so energies/forces do not depend on it
-    as long as no target exceeds max_num_neighbors);
-  * the per-step L-BFGS relaxation of the cap hydrogens (SURVEY.md 8f "next #1")
-    is not part of this round: cap hydrogens stay at their first-guess positions.
-CYX (disulfide) pair merging is not built yet (none of the example proteins has one).
+  /root/reference/src/Fragmentation/distancefrag.py:185-240,805-845 (CYX pairs: the two
+        dipeptides of a disulfide bridge become ONE fragment in the slot of the
+        first, the slot of the second stays empty)
+with one documented difference: atoms inside a fragment are ordered [previous-residue
+part | residue | next-residue part] instead of AMBER's order (the reference permutes with
+utils/seq_dict.pkl because its hydrogen optimiser needs AMBER topologies; ViSNet is
+permutation-equivariant, so energies/forces do not depend on it as long as no target
+exceeds max_num_neighbors; ai2bmd_amd/hydrogen.py maps rows to AMBER atoms by name).
+Pinned on the reference's own fragmenter (oracle/ref_fragmenter.py, tests/golden/fragref_*.npz).
+The per-step relaxation of the cap hydrogens is ai2bmd_amd/hydrogen.py + csrc/hydrogen.hip.
 """
 from __future__ import annotations
 
@@ -82,6 +83,10 @@ class FragmentPlan:
     select_index: np.ndarray  # int64 [K] rows of cat[...] that are original (non-cap) atoms
     origin_index: np.ndarray  # int64 [K] protein atom of every selected row
     energy_sign: np.ndarray   # float32 [B] +1 dipeptide, -1 ACE-NME (combiner.py:19)
+    # rows of every ORIGINAL dipeptide d (they differ from the fragment ranges when CYX pairs are merged)
+    dip_row_start: np.ndarray = None  # int64 [n_dip]
+    dip_row_end: np.ndarray = None    # int64 [n_dip]
+    cyx_partner: np.ndarray = None    # int64 [n_dip]: dipeptide merged INTO this one (-1 none, -2 = this one was merged away)
 
 
 def _residue_atom(p: ProteinAtoms, resnum: int, name: str) -> int:
@@ -98,8 +103,6 @@ def build_plan(p: ProteinAtoms) -> FragmentPlan:
     n_dip, n_ace = nres - 2, nres - 3
     if n_dip < 2:
         raise NotImplementedError("3 or fewer residues (incl. ACE/NME caps): use whole-molecule mode")
-    if (p.resnames == "CYX").any():
-        raise NotImplementedError("CYX pair merging is not built yet")
     resname_of = {int(r): str(p.resnames[np.flatnonzero(p.resnums == r)[0]]) for r in range(1, nres + 1)}
     if resname_of[1] != "ACE" or resname_of[nres] != "NME":
         raise ValueError("chain must be capped with ACE ... NME")
@@ -149,12 +152,40 @@ def build_plan(p: ProteinAtoms) -> FragmentPlan:
         acenmes.append(prev_part(k + 2) + next_part(k + 3))
         assert len(acenmes[-1]) == 12, len(acenmes[-1])
 
-    frags, is_dip = [], []
+    # disulfide bridges (distancefrag.py:805-845): CYX dipeptides paired by nearest SG-SG distance, first come first
+    # served; the pair becomes one fragment in the slot of the first, the second slot stays empty (:185-240)
+    cyx_partner = -np.ones(n_dip, dtype=np.int64)
+    cyx_dips = [d for d in range(n_dip) if resname_of[d + 2] == "CYX"]
+    if cyx_dips:
+        if len(cyx_dips) % 2:
+            raise ValueError("odd number of CYX residues")
+        sg = np.array([p.positions[_residue_atom(p, d + 2, "SG")] for d in cyx_dips], dtype=np.float64)
+        dist = np.linalg.norm(sg[None, :] - sg[:, None], axis=-1)
+        np.fill_diagonal(dist, np.inf)
+        pairs = {}
+        for i, j in enumerate(np.argmin(dist, axis=-1)):
+            if i in pairs or int(j) in pairs:
+                continue
+            pairs[i] = int(j)
+        for i, j in pairs.items():
+            cyx_partner[cyx_dips[i]] = cyx_dips[j]
+            cyx_partner[cyx_dips[j]] = -2
+
+    frags, is_dip, dip_of_frag_rows = [], [], []
     for d in range(n_dip):  # interleave dip0, ace0, dip1, ... (distancefrag.py:250-255)
-        frags.append(dipeptides[d])
+        if cyx_partner[d] == -2:
+            frags.append([])
+            dip_of_frag_rows.append([])
+        elif cyx_partner[d] >= 0:
+            frags.append(dipeptides[d] + dipeptides[int(cyx_partner[d])])
+            dip_of_frag_rows.append([(d, len(dipeptides[d])), (int(cyx_partner[d]), len(dipeptides[int(cyx_partner[d])]))])
+        else:
+            frags.append(dipeptides[d])
+            dip_of_frag_rows.append([(d, len(dipeptides[d]))])
         is_dip.append(True)
         if d < n_ace:
             frags.append(acenmes[d])
+            dip_of_frag_rows.append([])
             is_dip.append(False)
     sizes = np.array([len(f) for f in frags], dtype=np.int64)
     end = np.cumsum(sizes)
@@ -177,8 +208,15 @@ def build_plan(p: ProteinAtoms) -> FragmentPlan:
                 z[row] = 1
             row += 1
     is_dip = np.array(is_dip)
+    dip_row_start = np.zeros(n_dip, dtype=np.int64)
+    dip_row_end = np.zeros(n_dip, dtype=np.int64)
+    for fi, parts in enumerate(dip_of_frag_rows):
+        r0 = int(start[fi])
+        for d, n in parts:
+            dip_row_start[d], dip_row_end[d] = r0, r0 + n
+            r0 += n
     # cat[F_dip, F_ace] row order: all dipeptide rows in order, then all ACE-NME rows
-    dip_rows = np.concatenate([np.arange(start[b], end[b]) for b in range(len(frags)) if is_dip[b]])
+    dip_rows = np.concatenate([np.arange(start[b], end[b]) for b in range(len(frags)) if is_dip[b]]).astype(np.int64)
     ace_rows = np.concatenate([np.arange(start[b], end[b]) for b in range(len(frags)) if not is_dip[b]])
     row_of_cat = np.concatenate([dip_rows, ace_rows]).astype(np.int64)
     keep = src[row_of_cat] >= 0
@@ -188,6 +226,7 @@ def build_plan(p: ProteinAtoms) -> FragmentPlan:
         n_prot=len(p), z=z, start=start, end=end, src=src, acceptor=acc, toward=tow, length=length,
         is_dipeptide=is_dip, n_dip_rows=int(len(dip_rows)), row_of_cat=row_of_cat, select_index=select_index,
         origin_index=origin_index, energy_sign=np.where(is_dip, 1.0, -1.0).astype(np.float32),
+        dip_row_start=dip_row_start, dip_row_end=dip_row_end, cyx_partner=cyx_partner,
     )
 
 

@@ -44,15 +44,16 @@ class HydrogenPlan:
     occ_w: np.ndarray       # float32 energy share of this occurrence (1 / number of cap atoms in the term)
 
 
-def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, b: int, tmpl) -> np.ndarray:
-    """Template atom index of every row of dipeptide fragment b (matching by atom name)."""
-    names = [str(n) for n in tmpl["atom_names"]]
+def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, d: int, names) -> np.ndarray:
+    """Template atom index (within `names`, the atom names of one ACE-X-NME template) of every row of the
+    original dipeptide d, matching by atom name."""
+    names = [str(n) for n in names]
     nat = len(names)
-    rows = np.arange(plan.start[b], plan.end[b])
+    rows = np.arange(plan.dip_row_start[d], plan.dip_row_end[d])
     if len(rows) != nat:
-        raise ValueError(f"dipeptide {b}: {len(rows)} atoms, template has {nat}")
+        raise ValueError(f"dipeptide {d}: {len(rows)} atoms, template has {nat}")
     src = plan.src[rows]
-    d = b // 2
+    b = d
     r = d + 2  # central residue number (1-based, ACE = 1)
     out = -np.ones(nat, dtype=np.int64)
     resnum = np.where(src >= 0, p.resnums[np.maximum(src, 0)], 0)
@@ -133,11 +134,23 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
 
     for b in range(0, B, 2):
         d = b // 2
+        if plan.cyx_partner[d] == -2:  # merged into its disulfide partner's fragment
+            tmpl_index.append(np.zeros(0, dtype=np.int64))
+            continue
         code = TOPOLOGY_OF[resname_of[d + 2]]
         t = tables[code]
-        ti = template_index_of_dipeptide(p, plan, b, t)
+        if plan.cyx_partner[d] >= 0:
+            # CYX pair: one 44-atom AMBER topology = two ACE-CYX-NME halves bridged by the S-S bond
+            # (utils/reference.py:41,71; distancefrag.py:185-240); halves in the order (this, partner)
+            half = t["natom"] // 2
+            nm = t["atom_names"]
+            ti = np.concatenate([template_index_of_dipeptide(p, plan, d, nm[:half]),
+                                 half + template_index_of_dipeptide(p, plan, int(plan.cyx_partner[d]), nm[half:])])
+        else:
+            ti = template_index_of_dipeptide(p, plan, d, t["atom_names"])
         tmpl_index.append(ti)
         rows = np.arange(plan.start[b], plan.end[b])
+        assert len(rows) == len(ti)
         row_of_tmpl = np.empty(len(rows), dtype=np.int64)
         row_of_tmpl[ti] = rows
         capmask_t = np.zeros(len(rows), dtype=bool)
@@ -215,8 +228,8 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
     for b in range(1, B, 2):
         k = b // 2  # ACE-NME k: acetyl part of dipeptide k+1 (its first-residue rows), amide part of dipeptide k
         rows = np.arange(plan.start[b], plan.end[b])
-        dn = np.arange(plan.start[2 * (k + 1)], plan.end[2 * (k + 1)])  # dipeptide k+1
-        dp = np.arange(plan.start[2 * k], plan.end[2 * k])              # dipeptide k
+        dn = np.arange(plan.dip_row_start[k + 1], plan.dip_row_end[k + 1])  # dipeptide k+1
+        dp = np.arange(plan.dip_row_start[k], plan.dip_row_end[k])          # dipeptide k
 
         def key(rw):
             return (int(plan.src[rw]), int(plan.acceptor[rw]), int(plan.toward[rw]))

@@ -17,14 +17,51 @@ from ai2bmd_amd.fragmentation import ProteinAtoms  # noqa: E402
 from oracle.ref_fragmenter import run_reference_fragmenter  # noqa: E402
 
 
+def chig_with_disulfide(p):
+    """Chignolin (pre-processed atom order) with TYR-3 and THR-7 turned into a CYX-CYX bridge (their dipeptides share
+    no atom, and neither is the last one: the reference indexes past the end when the emptied slot is the last): backbone and CB kept, OG1 / CG -> SG (1.81 A from CB), HB / HB2 -> HB2, CG2 / HB3 -> HB3 (1.09 A), the
+    other side-chain atoms dropped; atoms in the pre-processed order N CA C O H HA CB SG HB2 HB3.  The geometry is not
+    physical (the two SG are far apart) - the fixture exists to exercise the reference's CYX index algebra, none of
+    its examples has a bridge."""
+    rule = {7: {"OG1": ("SG", 16, 1.81), "HB": ("HB2", 1, 1.09), "CG2": ("HB3", 1, 1.09)},
+            3: {"CG": ("SG", 16, 1.81), "HB2": ("HB2", 1, 1.09), "HB3": ("HB3", 1, 1.09)}}
+    rows = []
+    for i in range(len(p.numbers)):
+        r, nm = int(p.resnums[i]), str(p.names[i])
+        if r in rule:
+            if nm in ("N", "CA", "C", "O", "H", "HA", "CB"):
+                rows.append((r, nm, "CYX", int(p.numbers[i]), p.positions[i]))
+            elif nm in rule[r]:
+                cb = p.positions[np.flatnonzero((p.resnums == r) & (p.names == "CB"))[0]]
+                u = p.positions[i] - cb
+                new, z, ln = rule[r][nm]
+                rows.append((r, new, "CYX", z, cb + ln * u / np.linalg.norm(u)))
+        else:
+            rows.append((r, nm, str(p.resnames[i]), int(p.numbers[i]), p.positions[i]))
+    out = []
+    for r in sorted({x[0] for x in rows}):
+        grp = [x for x in rows if x[0] == r]
+        if grp[0][2] == "CYX":
+            want = ["N", "CA", "C", "O", "H", "HA", "CB", "SG", "HB2", "HB3"]
+            grp = [next(x for x in grp if x[1] == w) for w in want]
+        out += grp
+    return ProteinAtoms(names=np.array([x[1] for x in out]), resnames=np.array([x[2] for x in out]),
+                        resnums=np.array([x[0] for x in out]), numbers=np.array([x[3] for x in out]),
+                        positions=np.array([x[4] for x in out], dtype=np.float64))
+
+
 def main():
     # only the PRE-PROCESSED example: the reference's permutation tables (utils/seq_dict.pkl) assume the atom order its
     # own preprocessing (external AmberTools) writes; on the raw examples/*.pdb its fragmenter pairs atomic numbers
     # with the wrong rows.  Chignolin covers TYR ASP PRO GLU THR GLY TRP incl. the PRO / GLY neighbour special cases.
-    for name in ("chig",):
-        z = np.load(os.path.join(ROOT, "tests", "golden", f"protein_{name}.npz"))
+    for name in ("chig", "chigcyx"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", "protein_chig.npz"))
         p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
                          positions=z["positions"])
+        if name == "chigcyx":
+            p = chig_with_disulfide(p)
+            np.savez_compressed(os.path.join(ROOT, "tests", "golden", "protein_chigcyx.npz"), names=p.names,
+                                resnames=p.resnames, resnums=p.resnums, numbers=p.numbers, positions=p.positions)
         r = run_reference_fragmenter(p)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"fragref_{name}.npz"),
                             z=r["z"].astype(np.int16), pos=r["pos"].astype(np.float32),

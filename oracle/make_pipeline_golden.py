@@ -91,16 +91,13 @@ def reference_hydrogen_batch(CTable, resi_info, lengths, constrain_index, fragme
     return types.SimpleNamespace(pos=None, **{k: torch.cat(v) for k, v in cat.items()})
 
 
-def main():
-    CTable, HydrogenOptimizer = reference_modules()        # reference ctable.py / energies.py
-    DF = ref_fragmenter.load_distance_fragment()           # reference basefrag.py / distancefrag.py
-    fragment_info = sys.modules["utils.reference"].fragment_info
+def run_case(name, CTable, HydrogenOptimizer, DF, fragment_info):
     captured = {}
     DF.create_protein_graph = staticmethod(
         lambda resi_info, lengths, constrain: captured.update(resi_info=resi_info, lengths=lengths, constrain=constrain) or [])
     frag = DF()
     frag.optimizer = HydrogenOptimizer(10)                 # distancefrag.py:30-32
-    z = np.load(os.path.join(ROOT, "tests", "golden", "protein_chig.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"protein_{name}.npz"))
     rng = np.random.default_rng(17)
     prot_pos = z["positions"] + 0.03 * rng.standard_normal(z["positions"].shape)  # a thermally displaced frame
     p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
@@ -114,28 +111,35 @@ def main():
     sd = make_state_dict(hp, seed=WEIGHT_SEED)
     e32, f32 = run_reference(hp, sd, fd.z, fd.pos, fd.start, fd.end, torch.float32)
     e64, f64 = run_reference(hp, sd, fd.z, fd.pos.astype(np.float64), fd.start, fd.end, torch.float64)
+    comb = sys.modules["Calculators.combiner"].DipeptideBondedCombiner
     out = {}
     for tag, e, f in (("32", e32, f32), ("64", e64, f64)):
         e_t, f_t = torch.as_tensor(e).reshape(-1), torch.as_tensor(f)
         e_dip, e_ace = (e_t[s] for s in fd.scalar_split())
         f_dip, f_ace = (f_t[s] for s in fd.vector_split())
-        comb = sys.modules["Calculators.combiner"].DipeptideBondedCombiner if "Calculators.combiner" in sys.modules else None
-        if comb is None:
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("Calculators.combiner", "/root/reference/src/Calculators/combiner.py")
-            mod = importlib.util.module_from_spec(spec)
-            sys.path.insert(0, os.path.join(HERE, "shims"))
-            spec.loader.exec_module(mod)
-            sys.modules["Calculators.combiner"] = mod
-            comb = mod.DipeptideBondedCombiner
         out[f"E{tag}"] = np.float64(comb.energy_combine(e_dip, e_ace))
         out[f"F{tag}"] = comb.forces_combine(len(prot), f_dip, f_ace, prot.select_index, prot.origin_index).astype(np.float64)
-    print(f"chig: B={len(fd.start)} N={len(fd.z)}  E32 {out['E32']:.6f} E64 {out['E64']:.6f}  "
+    print(f"{name}: B={len(fd.start)} N={len(fd.z)}  E32 {out['E32']:.6f} E64 {out['E64']:.6f}  "
           f"max|F32-F64| {np.abs(out['F32'] - out['F64']).max():.2e}  max|F| {np.abs(out['F64']).max():.3f}")
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "pipeline_chig.npz"), prot_pos=prot_pos,
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"pipeline_{name}.npz"), prot_pos=prot_pos,
                         frag_pos=fd.pos.astype(np.float32), frag_z=np.asarray(fd.z).astype(np.int16),
                         weight_seed=WEIGHT_SEED, E32=out["E32"], E64=out["E64"], F32=out["F32"].astype(np.float32),
                         F64=out["F64"])
+
+
+def main():
+    import importlib.util
+
+    CTable, HydrogenOptimizer = reference_modules()        # reference ctable.py / energies.py
+    DF = ref_fragmenter.load_distance_fragment()           # reference basefrag.py / distancefrag.py
+    fragment_info = sys.modules["utils.reference"].fragment_info
+    sys.path.insert(0, os.path.join(HERE, "shims"))
+    spec = importlib.util.spec_from_file_location("Calculators.combiner", "/root/reference/src/Calculators/combiner.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sys.modules["Calculators.combiner"] = mod
+    for name in ("chig", "chigcyx"):                       # chigcyx: fabricated CYX-CYX bridge (make_fragmenter_golden)
+        run_case(name, CTable, HydrogenOptimizer, DF, fragment_info)
 
 
 if __name__ == "__main__":

@@ -105,19 +105,19 @@ def test_pipeline_with_relaxation_matches_host_composition(lib_built):
     np.testing.assert_allclose(F.cpu().numpy(), F_h, rtol=0, atol=5e-4)
 
 
-def test_device_pipeline_matches_reference_pipeline(lib_built):
+@pytest.mark.parametrize("name", ["chig", "chigcyx"])
+def test_device_pipeline_matches_reference_pipeline(lib_built, name):
     """the device-resident step (cap-H placement + HIP relaxation + HIP ViSNet + HIP combine) against the golden
     produced by the reference's own fragmenter, hydrogen optimiser, ViSNet source and combiner."""
     import os
 
-    from test_hydrogen import GOLD
+    from test_hydrogen import _pipeline_case
 
     from ai2bmd_amd.bonded import ShardedFragmentForces
     from ai2bmd_amd.synthetic import default_hparams, make_state_dict
     from ai2bmd_amd.visnet_calculator import ViSNetModel
 
-    p, plan, hp, _ = load_case("chig")
-    gold = np.load(os.path.join(GOLD, "pipeline_chig.npz"))
+    p, plan, hp, gold = _pipeline_case(name)  # "chigcyx": a CYX-CYX bridge (44-atom merged fragment + an empty slot)
     hparams = default_hparams(embedding_dimension=128, num_layers=3)
     model = ViSNetModel(hparams, make_state_dict(hparams, seed=int(gold["weight_seed"])), device="cuda:0")
     ff = ShardedFragmentForces.for_engine(model.engine, plan, hydrogen=hp)

@@ -32,12 +32,14 @@ def dipeptide_atom_lists(plan):
     return out
 
 
-def test_group_exclusion_equals_reference_pair_list():
+@pytest.mark.parametrize("name", ["chig", "chigcyx"])
+def test_group_exclusion_equals_reference_pair_list(name):
+    """"chigcyx": the two halves of a CYX pair are ONE dipeptide for the exclusion (distancefrag.py:195-197,355-363)"""
     from ai2bmd_amd.fragmentation import build_plan
     from ai2bmd_amd.nonbonded import dipeptide_groups
     from oracle.nonbonded_oracle import exclude_pairs_from_dipeptides, pair_list
 
-    prot = load_protein("chig")
+    prot = load_protein(name)
     plan = build_plan(prot)
     ex = exclude_pairs_from_dipeptides(dipeptide_atom_lists(plan))
     src, dst = pair_list(plan.n_prot, ex)
