@@ -21,7 +21,8 @@ with one documented difference: atoms inside a fragment are ordered [previous-re
 part | residue | next-residue part] instead of AMBER's order (the reference permutes with
 utils/seq_dict.pkl because its hydrogen optimiser needs AMBER topologies; ViSNet is
 permutation-equivariant, so energies/forces do not depend on it as long as no target
-exceeds max_num_neighbors; ai2bmd_amd/hydrogen.py maps rows to AMBER atoms by name).
+exceeds max_num_neighbors; ai2bmd_amd/hydrogen.py maps rows to AMBER atoms by name and
+`hydrogen.amber_ordered(plan)` gives the reference's row order when it is wanted).
 Pinned on the reference's own fragmenter (oracle/ref_fragmenter.py, tests/golden/fragref_*.npz).
 The per-step relaxation of the cap hydrogens is ai2bmd_amd/hydrogen.py + csrc/hydrogen.hip.
 """

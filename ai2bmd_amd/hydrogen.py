@@ -75,7 +75,9 @@ def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, d: int, nam
         for k in prev:
             out[k] = ace_names.index(name_of(k))
     else:
-        hs = [0, 2, 3]
+        # H1, then (H3, H2) - for the C-terminal dipeptide (H2, H3): the slot assignment the reference's permutation
+        # ends up with (distancefrag.py:570-620 puts the two new hydrogens in reverse order except at the C-terminus)
+        hs = [0, 2, 3] if d == len(plan.dip_row_start) - 1 else [0, 3, 2]
         for k in prev:
             nm = name_of(k)
             if nm == "CA":
@@ -84,7 +86,7 @@ def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, d: int, nam
                 out[k] = 4
             elif nm == "O":
                 out[k] = 5
-            else:  # HA / HA2 / HA3 / cap -> the three equivalent methyl hydrogens, in row order
+            else:  # HA / HA2 / HA3 / cap -> the three equivalent methyl hydrogens (same type and charge)
                 out[k] = hs.pop(0)
     # --- the residue itself
     for k in own:
@@ -247,6 +249,48 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
         occ_ptr=np.asarray(occ_ptr, np.int32), occ_type=np.asarray(ot, np.int32),
         occ_term=np.asarray(oterm, np.int32), occ_end=np.asarray(oend, np.int32), occ_w=np.asarray(ow, np.float32),
     )
+
+
+def amber_ordered(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> FragmentPlan:
+    """The same plan with the rows of every fragment in the REFERENCE's order: dipeptides in the atom order of their
+    AMBER topology (what utils/seq_dict.pkl produces, distancefrag.py:728-737), ACE-NME fragments as the first six
+    atoms of the next dipeptide followed by the last six of the previous one (distancefrag.py:291-302).  A
+    FragmentData built from it is row for row what `DistanceFragment.get_fragments` returns
+    (tests/test_fragmentation_and_sharding.py, against the reference's own fragmenter)."""
+    import dataclasses
+
+    hp = build_hydrogen_plan(p, plan, tables)
+    Nf = len(plan.z)
+    new_of_old = np.arange(Nf, dtype=np.int64)
+    slot_in_dip = {}
+    for b in range(0, len(plan.start), 2):
+        a0, ti = int(plan.start[b]), hp.tmpl_index[b // 2]
+        if len(ti):
+            new_of_old[a0:a0 + len(ti)] = a0 + ti
+    n_dip = len(plan.dip_row_start)
+    nat_of = plan.dip_row_end - plan.dip_row_start
+    for b in range(1, len(plan.start), 2):
+        a0 = int(plan.start[b])
+        for j in range(12):
+            src_row = int(hp.alias[a0 + j])              # the dipeptide row this ACE-NME row is a copy of
+            d = int(np.flatnonzero((plan.dip_row_start <= src_row) & (src_row < plan.dip_row_end))[0])
+            # template slot of that row inside ITS dipeptide half (CYX pairs: second half is offset by 22)
+            frag = 2 * (d if plan.cyx_partner[d] != -2 else int(np.flatnonzero(plan.cyx_partner == d)[0]))
+            slot = int(hp.tmpl_index[frag // 2][src_row - int(plan.start[frag])])
+            half0 = 0 if plan.cyx_partner[d] != -2 else int(nat_of[frag // 2])
+            slot -= half0
+            new_of_old[a0 + j] = a0 + (slot if j < 6 else 6 + slot - (int(nat_of[d]) - 6))
+    assert sorted(new_of_old.tolist()) == list(range(Nf))
+    old_of_new = np.argsort(new_of_old)
+    fields = {k: getattr(plan, k)[old_of_new] for k in ("z", "src", "acceptor", "toward", "length")}
+    # cat[F_dip, F_ace] keeps the same fragment order; inside a fragment the rows follow the new order
+    is_dip_row = np.repeat(plan.is_dipeptide, plan.end - plan.start)
+    rows = np.arange(Nf)
+    row_of_cat = np.concatenate([rows[is_dip_row], rows[~is_dip_row]]).astype(np.int64)
+    keep = fields["src"][row_of_cat] >= 0
+    # original dipeptide row ranges move with their rows only through the in-fragment permutation (ranges unchanged)
+    return dataclasses.replace(plan, **fields, row_of_cat=row_of_cat, select_index=np.flatnonzero(keep).astype(np.int64),
+                               origin_index=fields["src"][row_of_cat][keep].astype(np.int64))
 
 
 class HydrogenRelaxer:

@@ -168,3 +168,24 @@ def test_plan_matches_reference_fragmenter(name):
     n_nonempty = int(((plan.end - plan.start) > 0).sum())  # energies exist for non-empty fragments only
     _, F_mine = combine_host(plan, np.zeros((n_nonempty, 1), np.float32), f_mine.astype(np.float32))
     np.testing.assert_allclose(F_mine, F_ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["chig", "chigcyx"])
+def test_amber_ordered_plan_is_row_identical_to_the_reference(name):
+    """ai2bmd_amd.hydrogen.amber_ordered: a FragmentData built from it equals, row for row, what the reference's
+    DistanceFragment produces - atomic numbers, first-guess positions, select/origin indices."""
+    from ai2bmd_amd.amber import load_tables
+    from ai2bmd_amd.fragmentation import build_plan, fragment_positions
+    from ai2bmd_amd.hydrogen import amber_ordered
+
+    prot = load_protein(name)
+    plan = amber_ordered(prot, build_plan(prot), load_tables(os.path.join(GOLDEN, "amber_tables.npz")))
+    ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
+    assert np.array_equal(plan.z, ref["z"])
+    assert np.array_equal(plan.start, ref["start"]) and np.array_equal(plan.end, ref["end"])
+    np.testing.assert_allclose(fragment_positions(plan, prot.positions), ref["pos"], atol=2e-5)
+    # the recombination map {row of cat[F_dip, F_ace] -> protein atom} is the same set of pairs (the reference lists
+    # them in protein-atom order inside each fragment, we list them in row order)
+    o = np.argsort(ref["select_index"])
+    assert np.array_equal(plan.select_index, ref["select_index"][o])
+    assert np.array_equal(plan.origin_index, ref["origin_index"][o])
