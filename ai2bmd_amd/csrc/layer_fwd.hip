@@ -218,6 +218,34 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D,
   edge_attn_body<V, S, WPN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// fused LayerNorm of the NEXT layer / read-out on one node row held by a wave (same arithmetic as k_node_norm)
+template <int V>
+__device__ __forceinline__ void node_layernorm_store(const NextNorm& nn, int i, int H, int lane, float (&xv)[V]) {
+  const float invH = 1.0f / (float)H;
+  float g[V], bta[V], sm_ = 0.f;
+  ldrow<V>(nn.gamma, lane, g);
+  ldrow<V>(nn.beta, lane, bta);
+#pragma unroll
+  for (int c = 0; c < V; ++c) sm_ += xv[c];
+  const float mean = wave_sum(sm_) * invH;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    xv[c] -= mean;
+    q += xv[c] * xv[c];
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) * invH + 1e-5f);
+  float n[V], hh[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    n[c] = xv[c] * rs;
+    hh[c] = n[c] * g[c] + bta[c];
+  }
+  strow<V>(nn.xn + (size_t)i * H, lane, n);
+  strow<V>(nn.xh + (size_t)i * nn.ldxh, lane, hh);
+  if (lane == 0) nn.rstd[i] = rs;
+}
+
 // ---- vector messages, their aggregation and the node update ---------------------
 // V_i[s] = sum_e vh_j[s]*s1_e + d_e[s]*s2_e ; dx = (sum_s vec1 vec2) o2 + o3 ;
 // dvec = vec3 o1 + V ; x += dx ; vec += dvec    (visnet_block.py:284-288,271-274,129-137)
@@ -257,7 +285,89 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
         for (int c = 0; c < V; ++c) Va[s][c] += vj[c] * s1[c] + ds * s2[c];
       }
     }
-    node_reduce<V, S, WPN>(Va, smem, lane, sub);
+    if constexpr (WPN > 1 && S <= WPN) {
+      // Small batches: instead of summing everything into wave 0 and letting it walk the S components alone,
+      // reduce-SCATTER the partial sums (wave s receives the node total of component s) and let the S waves
+      // update their component in parallel; only the channel-wise sum over s and the LayerNorm stay on wave 0.
+      __syncthreads();  // smem may still be read from the previous node
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+        if (s != sub) {
+          float* dst = smem + ((size_t)(s * (WPN - 1) + (sub < s ? sub : sub - 1)) * 64 + lane) * V;
+#pragma unroll
+          for (int c = 0; c < V; ++c) dst[c] = Va[s][c];
+        }
+      __syncthreads();
+      float tot[V], vdp[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) tot[c] = vdp[c] = 0.f;
+      if (sub < S) {
+        float own[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) own[c] = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+          if (s == sub) {
+#pragma unroll
+            for (int c = 0; c < V; ++c) own[c] = Va[s][c];
+          }
+        for (int w = 0; w < WPN; ++w) {  // fixed order over the waves -> deterministic
+          if (w == sub) {
+#pragma unroll
+            for (int c = 0; c < V; ++c) tot[c] += own[c];
+          } else {
+            const float* src_ = smem + ((size_t)(sub * (WPN - 1) + (w < sub ? w : w - 1)) * 64 + lane) * V;
+#pragma unroll
+            for (int c = 0; c < V; ++c) tot[c] += src_[c];
+          }
+        }
+        float o1[V], v1[V], v2[V], v3[V], vv[V];
+        ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+        const float* row = vp + ((size_t)i * S + sub) * 5 * H;
+        ldrow<V>(row, lane, v1);
+        ldrow<V>(row + H, lane, v2);
+        ldrow<V>(row + 2 * H, lane, v3);
+        ldrow<V>(vec + ((size_t)i * S + sub) * H, lane, vv);
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          vdp[c] = v1[c] * v2[c];
+          vv[c] += v3[c] * o1[c] + tot[c];
+        }
+        strow<V>(vec + ((size_t)i * S + sub) * H, lane, vv);
+        if (nn.xn) {  // fused VecLayerNorm("none") of the NEXT layer / read-out: vh = vec * weight
+          float w[V];
+          ldrow<V>(nn.wvec, lane, w);
+#pragma unroll
+          for (int c = 0; c < V; ++c) vv[c] *= w[c];
+          strow<V>(nn.vh + ((size_t)i * S + sub) * H, lane, vv);
+        }
+      }
+      __syncthreads();  // everybody is done reading the partial sums
+      if (sub > 0 && sub < S) {
+        float* dst = smem + ((size_t)(sub - 1) * 64 + lane) * V;
+#pragma unroll
+        for (int c = 0; c < V; ++c) dst[c] = vdp[c];
+      }
+      __syncthreads();
+      if (sub == 0) {
+        float vd[V], o2[V], o3[V], xv[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) vd[c] = vdp[c];
+        for (int s = 1; s < S; ++s) {
+          const float* src_ = smem + ((size_t)(s - 1) * 64 + lane) * V;
+#pragma unroll
+          for (int c = 0; c < V; ++c) vd[c] += src_[c];
+        }
+        ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+        ldrow<V>(o + (size_t)i * 3 * H + 2 * H, lane, o3);
+        ldrow<V>(x + (size_t)i * H, lane, xv);
+#pragma unroll
+        for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
+        strow<V>(x + (size_t)i * H, lane, xv);
+        if (nn.xn) node_layernorm_store<V>(nn, i, H, lane, xv);
+      }
+    } else {
+      node_reduce<V, S, WPN>(Va, smem, lane, sub);
     if (sub == 0) {
       float o1[V], o2[V], o3[V], vd[V];
       ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
@@ -292,31 +402,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
 #pragma unroll
       for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
       strow<V>(x + (size_t)i * H, lane, xv);
-      if (nn.xn) {  // fused LayerNorm of the NEXT layer / read-out (same arithmetic as k_node_norm)
-        const float invH = 1.0f / (float)H;
-        float g[V], bta[V], sm_ = 0.f;
-        ldrow<V>(nn.gamma, lane, g);
-        ldrow<V>(nn.beta, lane, bta);
-#pragma unroll
-        for (int c = 0; c < V; ++c) sm_ += xv[c];
-        const float mean = wave_sum(sm_) * invH;
-        float q = 0.f;
-#pragma unroll
-        for (int c = 0; c < V; ++c) {
-          xv[c] -= mean;
-          q += xv[c] * xv[c];
-        }
-        const float rs = 1.0f / sqrtf(wave_sum(q) * invH + 1e-5f);
-        float n[V], hh[V];
-#pragma unroll
-        for (int c = 0; c < V; ++c) {
-          n[c] = xv[c] * rs;
-          hh[c] = n[c] * g[c] + bta[c];
-        }
-        strow<V>(nn.xn + (size_t)i * H, lane, n);
-        strow<V>(nn.xh + (size_t)i * nn.ldxh, lane, hh);
-        if (lane == 0) nn.rstd[i] = rs;
-      }
+      if (nn.xn) node_layernorm_store<V>(nn, i, H, lane, xv);
+    }
     }
   }
 }
