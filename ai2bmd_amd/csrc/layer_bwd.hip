@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
 // of layer l-1 (k_bwd_node_norm + k_bwd_node_update in one pass: both are node-local, g_x / g_vec of the
 // node stay in registers between the two)
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(256) void k_bwd_norm_update(Dims D, const float* __restrict__ g_xh, int ldg,
+__global__ __launch_bounds__(WPN == 1 ? 256 : 64 * WPN) void k_bwd_norm_update(Dims D, const float* __restrict__ g_xh, int ldg,
                                                          const float* __restrict__ g_vh,
                                                          const float* __restrict__ xn,
                                                          const float* __restrict__ rstd,
@@ -501,6 +501,101 @@ __global__ __launch_bounds__(256) void k_bwd_norm_update(Dims D, const float* __
                                                          float* __restrict__ g_o, float* __restrict__ g_vp) {
   const int H = D.H;
   const float invH = 1.0f / (float)H;
+  if constexpr (WPN > 1 && S <= WPN) {
+    // Small batches: wave s of the node's workgroup owns vector component s (every wave recomputes the cheap
+    // LayerNorm adjoint g_x); the two channel-wise sums over s go through LDS in a fixed order.
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    VSN_NODE_LOOP(i, D.N, WPN) {
+      float g[V], n[V], ga[V], w[V];
+      ldrow<V>(g_xh + (size_t)i * ldg, lane, g);
+      ldrow<V>(xn + (size_t)i * H, lane, n);
+      ldrow<V>(gamma, lane, ga);
+      ldrow<V>(wvec, lane, w);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        g[c] *= ga[c];
+        s1 += g[c];
+        s2 += g[c] * n[c];
+      }
+      const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+      const float rs = rstd[i];
+      float gx[V];
+      if (accumulate)
+        ldrow<V>(g_x + (size_t)i * H, lane, gx);
+      else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) gx[c] = 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) gx[c] += rs * (g[c] - m1 - n[c] * m2);
+      __syncthreads();  // all waves have read the old g_x row; smem of the previous node is free
+      if (sub == 0) strow<V>(g_x + (size_t)i * H, lane, gx);
+      float vdp[V], go1p[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) vdp[c] = go1p[c] = 0.f;
+      if (sub < S) {
+        const int s = sub;
+        float o1[V], o2[V], gv[V], ov[V];
+        ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
+        ldrow<V>(o + (size_t)i * 3 * H + H, lane, o2);
+        ldrow<V>(g_vh + ((size_t)i * S + s) * H, lane, gv);
+        if (accumulate)
+          ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, ov);
+        else {
+#pragma unroll
+          for (int c = 0; c < V; ++c) ov[c] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < V; ++c) ov[c] += gv[c] * w[c];
+        strow<V>(g_vec + ((size_t)i * S + s) * H, lane, ov);
+        const float* row = vp + ((size_t)i * S + s) * 5 * H;
+        float* grow = g_vp + ((size_t)i * S + s) * 5 * H;
+        float v1[V], v2[V], v3[V], t1[V], t2[V], t3[V];
+        ldrow<V>(row, lane, v1);
+        ldrow<V>(row + H, lane, v2);
+        ldrow<V>(row + 2 * H, lane, v3);
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          const float gvd = gx[c] * o2[c];
+          vdp[c] = v1[c] * v2[c];
+          go1p[c] = ov[c] * v3[c];
+          t1[c] = gvd * v2[c];
+          t2[c] = gvd * v1[c];
+          t3[c] = ov[c] * o1[c];
+        }
+        strow<V>(grow, lane, t1);
+        strow<V>(grow + H, lane, t2);
+        strow<V>(grow + 2 * H, lane, t3);
+        if (sub > 0) {
+          float* dst = smem + ((size_t)(sub - 1) * 2 * 64 + lane) * V;
+#pragma unroll
+          for (int c = 0; c < V; ++c) {
+            dst[c] = vdp[c];
+            dst[64 * V + c] = go1p[c];
+          }
+        }
+      }
+      __syncthreads();
+      if (sub == 0) {
+        for (int s = 1; s < S; ++s) {
+          const float* src_ = smem + ((size_t)(s - 1) * 2 * 64 + lane) * V;
+#pragma unroll
+          for (int c = 0; c < V; ++c) {
+            vdp[c] += src_[c];
+            go1p[c] += src_[64 * V + c];
+          }
+        }
+        float go2[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) go2[c] = gx[c] * vdp[c];
+        strow<V>(g_o + (size_t)i * 3 * H, lane, go1p);
+        strow<V>(g_o + (size_t)i * 3 * H + H, lane, go2);
+        strow<V>(g_o + (size_t)i * 3 * H + 2 * H, lane, gx);
+      }
+    }
+    return;
+  }
   VSN_NODE_LOOP(i, D.N, 1) {
     (void)sub;
     float g[V], n[V], ga[V], w[V];
@@ -719,9 +814,10 @@ int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int
                            int accumulate, float* g_x, float* g_vec, const float* vp, const float* o, float* g_o,
                            float* g_vp) {
   if (D.N <= 0) return 0;
-  VSN_DISPATCH_VS(D.H, D.S, 1, k_bwd_norm_update,
-                  <<<node_grid(D.N, 1), 256, 0, st>>>(D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x,
-                                                      g_vec, vp, o, g_o, g_vp));
+  const int w__ = pick_wpn(D.N);
+  VSN_DISPATCH_VS(D.H, D.S, w__, k_bwd_norm_update,
+                  <<<node_grid(D.N, w__), node_block(w__), w__ == 1 ? 0 : (size_t)(w__ - 1) * 2 * D.H * 4, st>>>(
+                      D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x, g_vec, vp, o, g_o, g_vp));
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
