@@ -137,3 +137,44 @@ __device__ __forceinline__ void node_reduce(float (&acc)[K][V], float* __restric
     }
   }
 }
+
+// Reduce-SCATTER over the WPN waves of the workgroup: wave s (s < K <= WPN) receives, in tot[], the sum over all waves
+// of acc[s][] (fixed order -> deterministic); every wave then finishes / stores its own row in parallel instead of
+// wave 0 walking all K rows.  LDS: K*(WPN-1) rows of 64*V floats (same budget as node_reduce with K rows).
+template <int V, int K, int WPN>
+__device__ __forceinline__ void node_reduce_scatter(const float (&acc)[K][V], float (&tot)[V],
+                                                    float* __restrict__ smem, int lane, int sub) {
+  static_assert(K <= WPN, "one wave per row");
+  __syncthreads();  // smem may still be read from the previous use
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (k != sub) {
+      float* dst = smem + ((size_t)(k * (WPN - 1) + (sub < k ? sub : sub - 1)) * 64 + lane) * V;
+#pragma unroll
+      for (int c = 0; c < V; ++c) dst[c] = acc[k][c];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < V; ++c) tot[c] = 0.f;
+  if (sub < K) {
+    float own[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) own[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (k == sub) {
+#pragma unroll
+        for (int c = 0; c < V; ++c) own[c] = acc[k][c];
+      }
+    for (int w = 0; w < WPN; ++w) {
+      if (w == sub) {
+#pragma unroll
+        for (int c = 0; c < V; ++c) tot[c] += own[c];
+      } else {
+        const float* src_ = smem + ((size_t)(sub * (WPN - 1) + (w < sub ? w : w - 1)) * 64 + lane) * V;
+#pragma unroll
+        for (int c = 0; c < V; ++c) tot[c] += src_[c];
+      }
+    }
+  }
+}

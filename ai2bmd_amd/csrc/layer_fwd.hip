@@ -289,38 +289,11 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
       // Small batches: instead of summing everything into wave 0 and letting it walk the S components alone,
       // reduce-SCATTER the partial sums (wave s receives the node total of component s) and let the S waves
       // update their component in parallel; only the channel-wise sum over s and the LayerNorm stay on wave 0.
-      __syncthreads();  // smem may still be read from the previous node
-#pragma unroll
-      for (int s = 0; s < S; ++s)
-        if (s != sub) {
-          float* dst = smem + ((size_t)(s * (WPN - 1) + (sub < s ? sub : sub - 1)) * 64 + lane) * V;
-#pragma unroll
-          for (int c = 0; c < V; ++c) dst[c] = Va[s][c];
-        }
-      __syncthreads();
       float tot[V], vdp[V];
+      node_reduce_scatter<V, S, WPN>(Va, tot, smem, lane, sub);
 #pragma unroll
-      for (int c = 0; c < V; ++c) tot[c] = vdp[c] = 0.f;
+      for (int c = 0; c < V; ++c) vdp[c] = 0.f;
       if (sub < S) {
-        float own[V];
-#pragma unroll
-        for (int c = 0; c < V; ++c) own[c] = 0.f;
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-          if (s == sub) {
-#pragma unroll
-            for (int c = 0; c < V; ++c) own[c] = Va[s][c];
-          }
-        for (int w = 0; w < WPN; ++w) {  // fixed order over the waves -> deterministic
-          if (w == sub) {
-#pragma unroll
-            for (int c = 0; c < V; ++c) tot[c] += own[c];
-          } else {
-            const float* src_ = smem + ((size_t)(sub * (WPN - 1) + (w < sub ? w : w - 1)) * 64 + lane) * V;
-#pragma unroll
-            for (int c = 0; c < V; ++c) tot[c] += src_[c];
-          }
-        }
         float o1[V], v1[V], v2[V], v3[V], vv[V];
         ldrow<V>(o + (size_t)i * 3 * H, lane, o1);
         const float* row = vp + ((size_t)i * S + sub) * 5 * H;
