@@ -8,8 +8,7 @@
 // Here: ONE kernel launch per step, one 1024-thread workgroup running the whole L-BFGS loop.  A cap hydrogen is always
 // an END atom of its bond / angle / dihedral terms, so its gradient is a closed form per term; the host resolves every
 // (cap, term) occurrence into a 32-byte record with the cap as first atom (all five energies are invariant under
-// reversing the atom order).  A wave gathers the occurrences of one cap (lane = occurrence) and reduces with xor
-// shuffles; every dot product / norm is a fixed-order workgroup reduction in fp64 - no atomics, bit-reproducible.
+// reversing the atom order).  Sixteen lanes gather the occurrences of one cap and reduce with xor shuffles; every dot product / norm is a fixed-order workgroup reduction in fp64 - no atomics, bit-reproducible.
 // The joint problem couples all dipeptides through the scalar step length and stop tests, so it is not sharded:
 // under multi-GPU every rank relaxes all caps redundantly (3*ncap unknowns, two energy evaluations in the usual case).
 #include <math.h>
@@ -123,27 +122,31 @@ __device__ __forceinline__ void occurrence(const int4 I, const float4 P, const V
   e *= P.w;
 }
 
-// loss and gradient at the current cap positions (held in `pos`); returns the loss to every thread
+// loss and gradient at the current cap positions (held in `pos`); returns the loss to every thread.
+// 16 lanes per cap hydrogen (a cap has ~40 term occurrences): 64 caps per pass of the 1024-thread workgroup.
 __device__ double evaluate(const HoptDev& a, const float* pos, float* g, double* sh) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
   double e_acc = 0.0;
-  for (int c = wave; c < a.ncap; c += HOPT_WAVES) {
-    const V3 x = ld3(pos, a.cap_row[c]);
-    const int o0 = a.occ_ptr[c], o1 = a.occ_ptr[c + 1];
+  for (int c0 = 0; c0 < a.ncap; c0 += HOPT_THREADS / 16) {  // uniform trip count: the shuffles below need every lane
+    const int c = c0 + grp;
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int o = o0 + lane; o < o1; o += 64) {
-      float e;
-      V3 gv;
-      occurrence(a.occ_i[o], a.occ_f[o], x, pos, e, gv);
-      e_acc += (double)e;
-      gx += gv.x;
-      gy += gv.y;
-      gz += gv.z;
+    if (c < a.ncap) {
+      const V3 x = ld3(pos, a.cap_row[c]);
+      const int o0 = a.occ_ptr[c], o1 = a.occ_ptr[c + 1];
+      for (int o = o0 + l; o < o1; o += 16) {
+        float e;
+        V3 gv;
+        occurrence(a.occ_i[o], a.occ_f[o], x, pos, e, gv);
+        e_acc += (double)e;
+        gx += gv.x;
+        gy += gv.y;
+        gz += gv.z;
+      }
     }
-    gx = wave_sum(gx);
-    gy = wave_sum(gy);
-    gz = wave_sum(gz);
-    if (lane == 0) {
+    gx = group_sum(gx, 16);
+    gy = group_sum(gy, 16);
+    gz = group_sum(gz, 16);
+    if (c < a.ncap && l == 0) {
       g[3 * c] = gx;
       g[3 * c + 1] = gy;
       g[3 * c + 2] = gz;
