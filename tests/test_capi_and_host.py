@@ -110,3 +110,51 @@ def test_fragment_data_mirror():
     assert sub.z.tolist() == list(range(22, 46)) and sub.batch.min() == 0
     one = fd[4]
     assert len(one) == 1 and one.pos.shape == (30, 3)
+
+
+def test_plan_entry_points_reject_bad_arguments(lib_built):
+    """errno-style codes, no crash: invalid plans are refused before any device work (-22 = EINVAL); on a host
+    without a GPU valid plans stop at device selection (-19 = ENODEV) instead of pretending to work."""
+    import torch
+
+    from ai2bmd_amd import capi
+
+    L = capi.lib()
+    h = C.c_void_p()
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    # combine plan: select / origin out of range
+    bad = L.vsn_combine_plan_create(C.byref(h), 0, 4, 6, 4, capi.i64_ptr(i64(range(6))), capi.i64_ptr(i64([0, 9])),
+                                    capi.i64_ptr(i64([0, 1])), 2)
+    assert bad == -22
+    bad = L.vsn_combine_plan_create(C.byref(h), 0, 4, 6, 4, capi.i64_ptr(i64(range(6))), capi.i64_ptr(i64([0, 1])),
+                                    capi.i64_ptr(i64([0, 7])), 2)
+    assert bad == -22
+    # fragment geometry plan: a cap hydrogen whose acceptor equals its direction atom
+    src, acc, tow = i64([0, -1]), i64([-1, 3]), i64([-1, 3])
+    ln = np.ascontiguousarray([0.0, 1.07], dtype=np.float32)
+    assert L.vsn_fragplan_create(C.byref(h), 0, 2, capi.i64_ptr(src), capi.i64_ptr(acc), capi.i64_ptr(tow),
+                                 ln.ctypes.data_as(C.POINTER(C.c_float))) == -22
+    # hydrogen optimiser: no caps / too many iterations / an occurrence that does not name the cap atom as an end atom
+    t = capi.VsnHoptTerms()
+    assert L.vsn_hopt_create(C.byref(h), 0, C.byref(t)) == -22
+    cap = i64([1])
+    occ_ptr = np.ascontiguousarray([0, 1], dtype=np.int32)
+    z32 = np.zeros(1, dtype=np.int32)
+    one = np.ones(1, dtype=np.float32)
+    bi, bj = np.ascontiguousarray([0], np.int32), np.ascontiguousarray([2], np.int32)  # bond 0-2 does not touch row 1
+    t.n_rows, t.n_cap, t.cap_rows = 3, 1, cap.ctypes.data_as(C.POINTER(C.c_int64))
+    t.n_bond = 1
+    t.bond_i, t.bond_j = bi.ctypes.data_as(C.POINTER(C.c_int32)), bj.ctypes.data_as(C.POINTER(C.c_int32))
+    t.bond_k, t.bond_r0 = one.ctypes.data_as(C.POINTER(C.c_float)), one.ctypes.data_as(C.POINTER(C.c_float))
+    t.occ_ptr = occ_ptr.ctypes.data_as(C.POINTER(C.c_int32))
+    t.occ_type = t.occ_term = t.occ_end = z32.ctypes.data_as(C.POINTER(C.c_int32))
+    t.occ_w = one.ctypes.data_as(C.POINTER(C.c_float))
+    t.max_iter, t.lr, t.tolerance_grad, t.tolerance_change, t.scnb, t.scee = 99, 0.1, 0.1, 0.01, 1.2, 2.0
+    assert L.vsn_hopt_create(C.byref(h), 0, C.byref(t)) == -22          # max_iter > 16
+    t.max_iter = 10
+    rc = L.vsn_hopt_create(C.byref(h), 0, C.byref(t))
+    assert rc == (-19 if not torch.cuda.is_available() else -22)          # ENODEV first on a GPU-less host
+    # MD / MM plans: non-positive sizes
+    assert L.vsn_md_create(C.byref(h), 0, 0, None, C.c_float(1.0), C.c_float(1.0), C.c_float(1.0), 0, C.c_float(0.0),
+                           None) == -22
+    assert L.vsn_combine_with_energy(None, None, None, None, None) == -22
