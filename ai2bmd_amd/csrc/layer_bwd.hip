@@ -129,6 +129,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
     }
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
+      const float geo_old = lane < S ? g_geo[(size_t)e * 24 + 16 + lane] : 0.f;  // fetched early, see k_bwd_vecmsg_T
       float u2[S][V], dd[S];
       float dot[V], a1[V], a2[V];
 #pragma unroll
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
         p = wave_sum(p);
         if (lane == s) mine = p;
       }
-      if (lane < S) g_geo[(size_t)e * 24 + 16 + lane] += mine;  // own slots: may run next to vecmsg_T
+      if (lane < S) g_geo[(size_t)e * 24 + 16 + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
     }
     node_reduce<V, S, WPN>(gwt, smem, lane, sub);
     if (sub == 0) {
@@ -245,6 +246,9 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
     for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
+      // the running dE/dd of this edge: fetched with the other operands, not after the reductions (a load that is
+      // issued only when the sum is ready stalls the wave for a full memory round trip per edge)
+      const float geo_old = lane < S ? g_geo[(size_t)e * 24 + lane] : 0.f;
       float t1[V], t2[V], s2[V], d1[V], d2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, t1);
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
         p = wave_sum(p);
         if (lane == s) mine = p;
       }
-      if (lane < S) g_geo[(size_t)e * 24 + lane] += mine;
+      if (lane < S) g_geo[(size_t)e * 24 + lane] = geo_old + mine;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gs1[c] *= d1[c];
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
       const float C = D.geo[(size_t)e * 8 + 1];
+      const float gC_old = lane == 0 ? g_geo[(size_t)e * 24 + 8] : 0.f;  // fetched early, see k_bwd_vecmsg_T
       float k[V], v[V], pk[V], pv[V], gm[V];
       ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
       ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       const float gsat = ga * dssat * C;
       const bool head_lead = (lane & (lph - 1)) == 0;
       const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
-      if (lane == 0) g_geo[(size_t)e * 24 + 8] += gC;
+      if (lane == 0) g_geo[(size_t)e * 24 + 8] = gC_old + gC;
       if (head_lead) {
         sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
         sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
