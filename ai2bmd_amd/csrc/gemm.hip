@@ -111,6 +111,20 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // accumulate mode on the one-accumulator tile (64x64, the grouped reverse-pass products): fetch the old C values
+  // now, so that the epilogue does not wait for a memory round trip per tile
+  constexpr bool PREC = (MI * NI == 1);
+  const bool accum = (flags & 1) != 0;
+  float cold[PREC ? 16 : 1];
+  if (PREC && accum && ksplit == 1) {
+    const int col = col0 + wn * TN + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = row0 + wm * TM + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      row = row < Meff ? row : Meff - 1;
+      cold[r] = C[(size_t)row * ldc + col];
+    }
+  }
   if (DB) {
     // software pipeline: LDS holds tile kt (buffer kt&1), registers hold tile kt+1, one barrier per tile
     VSN_GLOAD(kbase);
@@ -164,7 +178,6 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     __syncthreads();
   }
 
-  const bool accum = (flags & 1) != 0;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -178,7 +191,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
           if (ksplit == 1) {
             float* cp = C + (size_t)row * ldc + col;
             float v = acc[i][j][r] + bv;
-            if (accum) v += *cp;
+            if (accum) v += PREC ? cold[r] : *cp;
             *cp = v;
           } else {
             part[((size_t)ks * M + row) * Nc + col] = acc[i][j][r];
