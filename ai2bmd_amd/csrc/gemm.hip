@@ -116,6 +116,9 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   constexpr bool PREC = (MI * NI == 1);
   const bool accum = (flags & 1) != 0;
   float cold[PREC ? 16 : 1];
+  float bvs[NI];  // the bias too: one load per lane, but at the end of the tile it is a full round trip on the tail
+#pragma unroll
+  for (int j = 0; j < NI; ++j) bvs[j] = (bias && ksplit == 1) ? bias[col0 + wn * TN + j * 32 + l31] : 0.f;
   if (PREC && accum && ksplit == 1) {
     const int col = col0 + wn * TN + l31;
 #pragma unroll
@@ -183,7 +186,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = col0 + wn * TN + j * 32 + l31;
-      const float bv = (bias && ksplit == 1) ? bias[col] : 0.f;
+      const float bv = bvs[j];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
