@@ -114,10 +114,11 @@ def test_translation_rotation_and_net_force(lib_built):
         assert np.abs(f0[s:e_].sum(0)).max() < 2e-4
 
 
-def test_large_batch_properties(lib_built):
-    """A batch big enough to need the 128x128 GEMM tiles and many workgroups:
-    replicated fragments must give replicated results (a checksum of checksums)."""
-    hp = default_hparams(embedding_dimension=64, num_layers=2)
+@pytest.mark.parametrize("H,L", [(64, 2), (256, 3)])
+def test_large_batch_properties(lib_built, H, L):
+    """A batch big enough to need the 128x128 GEMM tiles and the one-wave-per-node gather kernels (N >= 4096):
+    replicated fragments must give replicated results (a checksum of checksums) that match the oracle."""
+    hp = default_hparams(embedding_dimension=H, num_layers=L)
     z1, p1, s1, e1 = random_fragments(5, [27, 12])
     reps = 200
     z = np.tile(z1, reps)
