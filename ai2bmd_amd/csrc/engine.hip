@@ -78,6 +78,8 @@ struct vsn_ctx {
   bool debug = false;
   bool profile = false;
   double prof[4][4] = {{0}};  // per GEMM kernel (128x128, 64x64, 128x32, grouped 64x64): launches, ms, flops, bytes
+  double prof_empty_ms = 0;   // profile mode: total time of EMPTY event brackets (the cost an event pair adds) ...
+  double prof_empty_n = 0;    // ... and how many were measured
   int64_t max_chunk_edges = 1048576;  // ~84 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s)
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
@@ -106,7 +108,15 @@ struct vsn_ctx {
   std::map<std::string, size_t> snap_elems;
   // last chunk dims
   int lastN = 0, lastB = 0, lastEmax = 0;
+  // fragment offsets of the last chunk as uploaded (MD: static fragmentation -> the upload is skipped).  The
+  // cache is valid only for the workspace it was uploaded into and the stream it was ordered on.
   std::vector<int> h_fs, h_fe;
+  hipStream_t h_fs_stream = nullptr;
+  int* pin_fs = nullptr;       // pinned staging for the upload (2 x pin_cap ints)
+  size_t pin_cap = 0;
+  hipEvent_t ev_upload = nullptr;  // recorded after the last upload: the staging buffer is free once it has fired
+  int n_atomref = 0;           // rows of the Atomref table (prior_args.max_z; independent of hparams.max_z)
+  int* status = nullptr;       // device status flag of the last chunk
 };
 
 static int fail(vsn_ctx* c, int code, const std::string& msg) {
@@ -144,7 +154,8 @@ extern "C" int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id)
   if (hipSetDevice(device_id) != hipSuccess) return fail(c, -19, "hipSetDevice failed (no MI355X visible?)");
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming) != hipSuccess)
     return fail(c, -5, "stream/event creation failed");
   return 0;
 }
@@ -157,6 +168,8 @@ extern "C" void vsn_destroy(vsn_handle c) {
   if (c->side) hipStreamDestroy(c->side);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
+  if (c->ev_upload) hipEventDestroy(c->ev_upload);
+  if (c->pin_fs) hipHostFree(c->pin_fs);
   for (auto& kv : c->snap)
     for (float* p : kv.second)
       if (p) hipFree(p);
@@ -198,6 +211,7 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
   } else if (k == "profile") {
     c->profile = value != 0;
     memset(c->prof, 0, sizeof(c->prof));
+    c->prof_empty_ms = c->prof_empty_n = 0;
   } else {
     return fail(c, -22, "unknown option " + k);
   }
@@ -397,8 +411,12 @@ extern "C" int vsn_finalize(vsn_handle c) {
   }
   bool has_ar = c->hp.has_atomref != 0;
   if (has_ar) {
-    NEED(ar, "prior_model.atomref.weight", (size_t)Z);
-    off["atomref"] = P.add(*ar);
+    // the Atomref table takes its size from prior_args["max_z"] (ViSNet/model/priors.py:62-77), not from the
+    // model's max_z: accept any length and bounds-check z against both tables (graph.hip::k_graph_count)
+    auto it = c->raw.find("prior_model.atomref.weight");
+    if (it == c->raw.end() || it->second.data.empty()) return fail(c, -2, "missing tensor prior_model.atomref.weight");
+    c->n_atomref = (int)it->second.data.size();
+    off["atomref"] = P.add(it->second.data);
   }
 #undef NEED
 
@@ -550,7 +568,7 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
   c->g_pp = a.take<float>(e * 2 * H);
   c->g_n = a.take<float>(n * H);
   c->g_rbf = a.take<float>(e * Rp);
-  c->g_geo = a.take<float>(e * VSN_GEO_W);
+  c->g_geo = a.take<float>(e * VSN_GEO_W + 64);  // + the chunk's status word, cleared by the same memset
   c->g_ev = a.take<float>(e * 4);
   // split-K partials: up to 8 slices of the widest narrow output ([E,H] or [S*N,H])
   c->splitk_elems = 8 * std::max(e, n * S) * H;
@@ -567,6 +585,10 @@ static int ensure_ws(vsn_ctx* c, int N, int E, int Bn) {
   c->ws.dry = true;
   carve(c, nN, nE, nB);
   size_t need = c->ws.off;
+  // the cached fragment offsets live in the workspace: a re-carve (or a failed one) invalidates them
+  c->h_fs.clear();
+  c->h_fe.clear();
+  c->h_fs_stream = nullptr;
   if (c->ws.base) {
     HIPCHK(c, hipDeviceSynchronize());
     hipFree(c->ws.base);
@@ -614,11 +636,28 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   c->lastB = Bn;
   c->lastEmax = Emax;
   // fragment offsets (small) - skip the upload when unchanged (MD: static fragmentation)
-  if (fs != c->h_fs || fe != c->h_fe) {
+  if (fs != c->h_fs || fe != c->h_fe || st != c->h_fs_stream) {
+    // pinned staging buffer (an async copy from pageable memory may still read the source after the call
+    // returns); it is rewritten only after the previous upload has completed
+    if ((size_t)Bn > c->pin_cap) {
+      if (c->pin_fs) {
+        HIPCHK(c, hipEventSynchronize(c->ev_upload));
+        hipHostFree(c->pin_fs);
+        c->pin_fs = nullptr;
+      }
+      c->pin_cap = std::max<size_t>((size_t)Bn * 2, 1024);
+      HIPCHK(c, hipHostMalloc((void**)&c->pin_fs, 2 * c->pin_cap * sizeof(int), hipHostMallocDefault));
+    } else {
+      HIPCHK(c, hipEventSynchronize(c->ev_upload));
+    }
     c->h_fs = fs;
     c->h_fe = fe;
-    HIPCHK(c, hipMemcpyAsync(c->fstart, c->h_fs.data(), Bn * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->fend, c->h_fe.data(), Bn * sizeof(int), hipMemcpyHostToDevice, st));
+    c->h_fs_stream = st;
+    memcpy(c->pin_fs, fs.data(), Bn * sizeof(int));
+    memcpy(c->pin_fs + c->pin_cap, fe.data(), Bn * sizeof(int));
+    HIPCHK(c, hipMemcpyAsync(c->fstart, c->pin_fs, Bn * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->fend, c->pin_fs + c->pin_cap, Bn * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_upload, st));
   }
   GraphArgs g;
   g.pos = pos;
@@ -646,6 +685,10 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   g.tgt = c->tgt;
   g.perm = c->perm;
   g.ecount = c->ecount;
+  c->status = reinterpret_cast<int*>(c->g_geo + (size_t)Emax * VSN_GEO_W);
+  g.status = c->status;
+  g.z_limit = c->hw.atomref ? std::min(c->Z, c->n_atomref) : c->Z;
+  c->hw.status = c->status;
   g.geo = c->geo;
   g.d = c->d;
   g.rbf = c->rbf;
@@ -675,7 +718,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (r__) return fail(c, r__, std::string("launch failed: ") + #call); \
   } while (0)
 
-  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, (size_t)Emax * VSN_GEO_W * sizeof(float), st));
+  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, ((size_t)Emax * VSN_GEO_W + 16) * sizeof(float), st));  // incl. status
   HIPCHK(c, hipMemsetAsync(c->g_f, 0, (size_t)Emax * H * sizeof(float), st));
   RC(launch_graph(st, g));
   // ---- embeddings ----
@@ -891,7 +934,16 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       fe[(size_t)(b - b0)] = (int)(host_end[b] - a0);
     }
     GemmProfiler gp;
-    if (c->profile) set_gemm_profiler(&gp);
+    hipEvent_t empty[16];
+    if (c->profile) {
+      set_gemm_profiler(&gp);
+      // what an event bracket itself costs on this stream: 8 brackets around nothing, mid-stream (the device is
+      // busy with the previous chunk / step, as it is for the real brackets)
+      for (int k = 0; k < 16; ++k) {
+        hipEventCreate(&empty[k]);
+        hipEventRecord(empty[k], st);
+      }
+    }
     int rc0 = ensure_ws(c, (int)(a1 - a0), (int)eb, (int)(b1 - b0));
     if (rc0) return rc0;
     set_gemm_splitk_workspace(c->splitk, c->splitk_elems);
@@ -903,6 +955,14 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       hipStreamSynchronize(st);
       int E = 0;
       hipMemcpy(&E, c->ecount, sizeof(int), hipMemcpyDeviceToHost);
+      for (int k = 0; k < 16; k += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, empty[k], empty[k + 1]) == hipSuccess) {
+          c->prof_empty_ms += ms;
+          c->prof_empty_n += 1;
+        }
+      }
+      for (int k = 0; k < 16; ++k) hipEventDestroy(empty[k]);
       for (auto& r : gp.recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
@@ -936,6 +996,11 @@ extern "C" int vsn_profile_read(vsn_handle c, double* out16) {
   return 0;
 }
 
+extern "C" double vsn_profile_bracket_ms(vsn_handle c) {
+  if (!c || c->prof_empty_n <= 0) return 0.0;
+  return c->prof_empty_ms / c->prof_empty_n;
+}
+
 extern "C" int64_t vsn_last_num_edges(vsn_handle c) {
   if (!c || !c->ws.base) return -22;
   hipSetDevice(c->device);
@@ -943,6 +1008,15 @@ extern "C" int64_t vsn_last_num_edges(vsn_handle c) {
   int e = 0;
   if (hipMemcpy(&e, c->ecount, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -5;
   return e;
+}
+
+extern "C" int vsn_last_status(vsn_handle c) {
+  if (!c || !c->ws.base || !c->status) return -22;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  int v = 0;
+  if (hipMemcpy(&v, c->status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -5;
+  return v;
 }
 
 extern "C" int64_t vsn_debug_read(vsn_handle c, const char* name, int layer, void* host_out, int64_t max_elems) {

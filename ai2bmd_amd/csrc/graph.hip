@@ -23,10 +23,12 @@ __device__ __forceinline__ float dist2(const float* __restrict__ pos, int a, int
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
-// pass 1: truncated in-degree per target; also narrows z to int32
+// pass 1: truncated in-degree per target; also narrows z to int32.  An atomic number outside the embedding /
+// atomref tables (nn.Embedding raises IndexError in the reference) is clamped to row 0 and raises the chunk's
+// status flag; the final kernels then poison energies and forces with NaN and vsn_last_status() reports it.
 __global__ void k_graph_count(const float* __restrict__ pos, const long long* __restrict__ z64,
                               const int* __restrict__ fstart, const int* __restrict__ fend, int* __restrict__ deg,
-                              int* __restrict__ zi, float rc2, int max_nb) {
+                              int* __restrict__ zi, float rc2, int max_nb, int z_limit, int* __restrict__ status) {
   const int b = blockIdx.x;
   const int s = fstart[b], n = fend[b] - s;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -34,7 +36,10 @@ __global__ void k_graph_count(const float* __restrict__ pos, const long long* __
     for (int j = 0; j < n && cnt < max_nb; ++j)
       if (dist2(pos, s + j, s + i) < rc2) ++cnt;
     deg[s + i] = cnt;
-    zi[s + i] = (int)z64[s + i];
+    const long long zv = z64[s + i];
+    const bool bad = zv < 0 || zv >= (long long)z_limit;
+    if (bad) atomicOr(status, 1);
+    zi[s + i] = bad ? 0 : (int)zv;
   }
 }
 
@@ -311,7 +316,7 @@ __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restri
 // 16 lanes per atom stride over its ~17 in- and ~17 out-edges (one thread per atom walked 34 dependent loads).
 __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int* __restrict__ colptr,
                                const int* __restrict__ perm, const float* __restrict__ g_ev,
-                               float* __restrict__ f_out) {
+                               float* __restrict__ f_out, const int* __restrict__ status) {
   const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
   const bool live = i < N;
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -331,6 +336,7 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
   fx = group_sum(fx, 16);
   fy = group_sum(fy, 16);
   fz = group_sum(fz, 16);
+  if (*status) fx = fy = fz = __builtin_nanf("");  // invalid input (atomic number out of range): fail loudly
   if (live && l == 0) {
     f_out[3 * (size_t)i + 0] = fx;
     f_out[3 * (size_t)i + 1] = fy;
@@ -341,7 +347,7 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
 int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.B <= 0 || a.N <= 0) return 0;
   hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
-                     a.max_nb);
+                     a.max_nb, a.z_limit, a.status);
   hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
   if (a.max_frag <= 64) {
     hipLaunchKernelGGL(k_graph_fill_small, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr, a.src,
@@ -367,7 +373,7 @@ int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, cons
     hipLaunchKernelGGL(k_bwd_geom, dim3(blocks), dim3(256), 0, st, a.ecount, a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S,
                        g_ev);
   hipLaunchKernelGGL(k_force_gather, dim3((a.N + 15) / 16), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
-                     g_ev, f_out);
+                     g_ev, f_out, a.status);
   return 0;
 }
 

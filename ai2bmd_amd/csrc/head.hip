@@ -56,12 +56,13 @@ __global__ void hk_final(int N, int h2, const float* __restrict__ a1b, const flo
 }
 
 __global__ void hk_energy(int B, const int* __restrict__ fstart, const int* __restrict__ fend,
-                          const float* __restrict__ y, float mean, float* __restrict__ e_out) {
+                          const float* __restrict__ y, float mean, float* __restrict__ e_out,
+                          const int* __restrict__ status) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float acc = 0.f;
   for (int i = fstart[b]; i < fend[b]; ++i) acc += y[i];
-  e_out[b] = acc + mean;
+  e_out[b] = (status && *status) ? __builtin_nanf("") : acc + mean;
 }
 
 // ---- reverse ----
@@ -117,7 +118,8 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
                         const int* fstart, const int* fend, int B, float* e_out) {
   const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
   if (N <= 0) {
-    if (B > 0) hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out);
+    if (B > 0) hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
+                                  W.status);
     return 0;
   }
   int rc = 0;
@@ -134,7 +136,8 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
   rc |= launch_gemm(st, Bf.cat1, H, W.Wa1, H, Bf.a1b, h2, W.ba1, N, nullptr, h2, H, 0);
   hipLaunchKernelGGL(hk_final, dim3((N + 3) / 4), dim3(256), 0, st, N, h2, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
                      D.zi, Bf.y);
-  hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out);
+  hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
+                                  W.status);
   return rc;
 }
 

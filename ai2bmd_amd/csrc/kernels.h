@@ -26,6 +26,8 @@ struct GraphArgs {
   int* tgt;
   int* perm;
   int* ecount;
+  int z_limit;   // valid atomic numbers: 0 <= z < z_limit (embedding rows, atomref rows)
+  int* status;   // device flag of the chunk (bit 0: atomic number out of range); cleared by the engine
   float* geo;   // [E,8]  r, C, dC, ux, uy, uz, 1/r, 0
   float* d;     // [E,8]  spherical harmonics (first S used)
   float* rbf;   // [E,Rp]
@@ -162,6 +164,7 @@ struct HeadW {
   const float* wb1;  // [h2] row 0 of update_net.2 of block 1
   float bb1, mean, stdv;
   const float* atomref;  // [Z] or null
+  const int* status;     // chunk status flag (see GraphArgs): non-zero -> energies are NaN
 };
 struct HeadBuf {
   float *cat0, *pv0, *a0, *u0, *vec1o, *cat1, *p1, *a1b, *y;        // forward

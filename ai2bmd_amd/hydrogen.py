@@ -123,7 +123,7 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
     Nf = len(plan.z)
     B = len(plan.start)
     resname_of = {int(r): str(p.resnames[np.flatnonzero(p.resnums == r)[0]]) for r in set(p.resnums.tolist())}
-    bond = dict(i=[], j=[], k=[], r0=[])
+    bond = dict(i=[], j=[], kf=[], r0=[])
     angle = dict(i=[], j=[], k=[], kf=[], th0=[])
     dih = dict(i=[], j=[], k=[], l=[], kf=[], per=[], phase=[])
     pair = dict(i=[], j=[], A=[], B=[], qq=[])
@@ -163,7 +163,7 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
             if capmask_t[a] or capmask_t[c]:
                 term = len(bond["i"])
                 bond["i"].append(row_of_tmpl[a]); bond["j"].append(row_of_tmpl[c])
-                bond["k"].append(t["bond_force_constant"][idx]); bond["r0"].append(t["bond_equil_value"][idx])
+                bond["kf"].append(t["bond_force_constant"][idx]); bond["r0"].append(t["bond_equil_value"][idx])
                 n = int(capmask_t[a]) + int(capmask_t[c])
                 if capmask_t[a]:
                     add_occ(row_of_tmpl[a], 0, term, 0, n)
@@ -242,7 +242,8 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
             lut = lut_n if j < 6 else lut_p
             alias[rw] = lut[key(rw)]
 
-    f32 = lambda d_: {k_: np.asarray(v, dtype=np.int32 if k_ in "ijkl" else np.float32) for k_, v in d_.items()}
+    index_keys = ("i", "j", "k", "l")  # atom rows; every other key is a float parameter (force constants: "kf")
+    f32 = lambda d_: {k_: np.asarray(v, dtype=np.int32 if k_ in index_keys else np.float32) for k_, v in d_.items()}
     return HydrogenPlan(
         cap_rows=cap_rows, alias=alias, tmpl_index=tmpl_index,
         bond=f32(bond), angle=f32(angle), dihedral=f32(dih), pair=f32(pair),
@@ -317,7 +318,7 @@ class HydrogenRelaxer:
         t.cap_rows, t.alias = P(i64(hplan.cap_rows), C.c_int64), P(i64(hplan.alias), C.c_int64)
         t.n_bond = len(b["i"])
         t.bond_i, t.bond_j = P(i32(b["i"]), C.c_int32), P(i32(b["j"]), C.c_int32)
-        t.bond_k, t.bond_r0 = P(f32(b["k"]), C.c_float), P(f32(b["r0"]), C.c_float)
+        t.bond_k, t.bond_r0 = P(f32(b["kf"]), C.c_float), P(f32(b["r0"]), C.c_float)
         t.n_angle = len(a["i"])
         t.angle_i, t.angle_j, t.angle_k = (P(i32(a[k]), C.c_int32) for k in "ijk")
         t.angle_kf, t.angle_th0 = P(f32(a["kf"]), C.c_float), P(f32(a["th0"]), C.c_float)

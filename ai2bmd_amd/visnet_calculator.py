@@ -107,8 +107,28 @@ class ViSNetEngine:
         return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], flops=out[4 * v + 2], bytes=out[4 * v + 3])
                 for v in range(4)}
 
+    def profile_bracket_ms(self) -> float:
+        """Average cost of an empty HIP-event bracket measured in the profiled calls (subtract it per launch)."""
+        return float(self._L.vsn_profile_bracket_ms(self._h))
+
     def last_num_edges(self) -> int:
         return int(self._L.vsn_last_num_edges(self._h))
+
+    @property
+    def z_limit(self) -> int:
+        """Atomic numbers must satisfy 0 <= z < z_limit (rows of the embedding tables and of the Atomref table)."""
+        lim = int(self.hparams["max_z"])
+        ar = self.weights.get("prior_model.atomref.weight")
+        return min(lim, int(ar.numel())) if ar is not None and self.hparams.get("prior_model") == "Atomref" else lim
+
+    def check_status(self):
+        """Synchronises; raises IndexError if the last chunk saw an atomic number outside the tables (the kernels
+        clamp the index and NaN-poison that chunk's outputs; nn.Embedding raises in the reference)."""
+        st = int(self._L.vsn_last_status(self._h))
+        if st < 0:
+            self._check(st)
+        if st & 1:
+            raise IndexError(f"atomic number outside [0, {self.z_limit}) in the last fragment batch")
 
     def debug_read(self, name: str, layer: int = 0, dtype=np.float32, max_elems: int = 1 << 28) -> np.ndarray:
         # size query by reading into a generously sized buffer
@@ -166,6 +186,10 @@ class ViSNetModel:
 
     def dl_potential_loader(self, frag_data: FragmentData):
         """-> (e float32 [B_nonempty, 1], f float32 [N, 3]) as numpy, like the reference (:54-63)."""
+        z_host = np.asarray(frag_data.z)
+        if z_host.size and (z_host.min() < 0 or z_host.max() >= self.engine.z_limit):
+            # nn.Embedding / Atomref raise for an index outside their table (visnet_block.py:110, priors.py:86-87)
+            raise IndexError(f"atomic number outside [0, {self.engine.z_limit}) in FragmentData.z")
         with torch.cuda.stream(self.stream):
             d = self.collate(frag_data)
             B = len(d["start"])

@@ -52,7 +52,7 @@ typedef struct vsn_hparams {
   int32_t max_z;             /* embedding rows                                 */
   int32_t max_num_neighbors; /* radius_graph truncation (incl. the self loop)  */
   int32_t vecnorm_type;      /* VSN_VECNORM_*                                  */
-  int32_t has_atomref;       /* prior_model == "Atomref"                       */
+  int32_t has_atomref;       /* prior_model == "Atomref" (table length = prior_args.max_z, taken from the tensor) */
   float cutoff;              /* Angstrom                                       */
 } vsn_hparams;
 
@@ -93,9 +93,18 @@ int vsn_forces(vsn_handle h, const int64_t* dev_z, const float* dev_pos, const i
  * out[4v..4v+3] = {launches, total ms, total algorithmic flops, total algorithmic bytes}
  * accumulated since the option was set. */
 int vsn_profile_read(vsn_handle h, double* out16);
+/* Average time (ms) between the two events of an EMPTY bracket on the launch stream, measured in the same profiled
+ * calls (8 per chunk): what the bracket itself adds to every per-launch figure above.  0 when nothing was measured. */
+double vsn_profile_bracket_ms(vsn_handle h);
 
 /* Device-side edge count of the last chunk processed (synchronises). */
 int64_t vsn_last_num_edges(vsn_handle h);
+
+/* Device-side status word of the last chunk (synchronises): 0 = ok, bit 0 = an atomic number was outside
+ * [0, min(max_z, atomref rows)) - the reference's nn.Embedding raises IndexError there
+ * (ViSNet/model/visnet_block.py:110, priors.py:86-87); vsn_forces is asynchronous, so the kernels clamp the
+ * index (no out-of-bounds read) and write NaN to every energy and force of the chunk instead. */
+int vsn_last_status(vsn_handle h);
 
 /* Debug/verification: copies a named internal buffer of the LAST chunk to host
  * memory (synchronises).  Returns the number of floats (or int32s) written, or

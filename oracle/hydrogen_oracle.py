@@ -29,7 +29,7 @@ class HydrogenOracle:
         self.cap = _t(hplan.cap_rows, torch.long)
         L, D = torch.long, dtype
         b, a, d, p = hplan.bond, hplan.angle, hplan.dihedral, hplan.pair
-        self.b = (_t(b["i"], L), _t(b["j"], L), _t(b["k"], D), _t(b["r0"], D))
+        self.b = (_t(b["i"], L), _t(b["j"], L), _t(b["kf"], D), _t(b["r0"], D))
         self.a = (_t(a["i"], L), _t(a["j"], L), _t(a["k"], L), _t(a["kf"], D), _t(a["th0"], D))
         self.d = (_t(d["i"], L), _t(d["j"], L), _t(d["k"], L), _t(d["l"], L), _t(d["kf"], D), _t(d["per"], D), _t(d["phase"], D))
         self.p = (_t(p["i"], L), _t(p["j"], L), _t(p["A"], D), _t(p["B"], D), _t(p["qq"], D))

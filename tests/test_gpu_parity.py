@@ -255,3 +255,48 @@ def test_full_size_batch_properties_and_chunk_boundaries(lib_built):
     # chunk size changes the tile variant / reduction grouping, not the math: fp32 round-off only
     np.testing.assert_allclose(e2.reshape(reps, 2), e, rtol=0, atol=2e-5)
     np.testing.assert_allclose(f2.reshape(reps, n1, 3), f, rtol=0, atol=2e-5)
+
+
+def test_atomic_number_out_of_range_is_loud(lib_built):
+    """nn.Embedding raises for z >= max_z (visnet_block.py:110); the host seam raises IndexError, the
+    device-resident entry clamps the index, poisons the chunk with NaN and reports it through the status word."""
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    m = ViSNetModel(hp, make_state_dict(hp, seed=1), device="cuda:0")
+    z, pos, start, end = random_fragments(3, [12, 14])
+    bad = z.copy()
+    bad[5] = hp["max_z"] + 7
+    with pytest.raises(IndexError):
+        m.dl_potential_loader(frag(bad, pos, start, end))
+    zt, pt = torch.as_tensor(bad).cuda(), torch.as_tensor(pos).cuda()
+    e, f = torch.zeros(2, device="cuda"), torch.zeros(len(z), 3, device="cuda")
+    m.engine.forces_device(zt, pt, start, end, e, f)
+    torch.cuda.synchronize()
+    assert torch.isnan(e).all() and torch.isnan(f).all()
+    with pytest.raises(IndexError):
+        m.engine.check_status()
+    # the flag is per chunk: a valid batch afterwards is clean
+    m.engine.forces_device(torch.as_tensor(z).cuda(), pt, start, end, e, f)
+    m.engine.check_status()
+    assert torch.isfinite(e).all() and torch.isfinite(f).all()
+
+
+def test_atomref_table_shorter_than_max_z(lib_built):
+    """Atomref takes its size from prior_args.max_z (priors.py:62-77), independent of the model's max_z."""
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    sd = make_state_dict(hp, seed=2)
+    z, pos, start, end = random_fragments(4, [12, 20])
+    full = ViSNetModel(hp, sd, device="cuda:0").dl_potential_loader(frag(z, pos, start, end))
+    sd2 = dict(sd)
+    sd2["prior_model.atomref.weight"] = np.asarray(sd["prior_model.atomref.weight"])[:20].copy()
+    m = ViSNetModel(hp, sd2, device="cuda:0")
+    assert m.engine.z_limit == 20
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    assert (e == full[0]).all() and (f == full[1]).all()
+    zb = z.copy()
+    zb[0] = 25
+    with pytest.raises(IndexError):
+        m.dl_potential_loader(frag(zb, pos, start, end))

@@ -84,6 +84,25 @@ def test_oracle_matches_reference_optimizer(name):
         assert np.allclose(e1, gold[f"{tag}_e1"], rtol=2e-4, atol=2e-3) and e1.sum() < e0.sum()
 
 
+def test_non_integral_bond_force_constant_survives_the_plan():
+    """The bond dict's force constant must stay a float (a custom prmtop may hold non-integral constants)."""
+    import copy
+
+    z = np.load(os.path.join(GOLD, "protein_chig.npz"))
+    p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
+                     positions=z["positions"])
+    plan = build_plan(p)
+    tables = copy.deepcopy(load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    for t in tables.values():
+        t["bond_force_constant"] = np.asarray(t["bond_force_constant"], np.float64) + 0.37
+    hp = build_hydrogen_plan(p, plan, tables)
+    assert hp.bond["kf"].dtype == np.float32 and hp.bond["i"].dtype == np.int32
+    frac = hp.bond["kf"] - np.floor(hp.bond["kf"])
+    assert np.allclose(frac, 0.37, atol=1e-3)
+    ref = build_hydrogen_plan(p, plan, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    assert np.allclose(hp.bond["kf"], ref.bond["kf"] + 0.37, atol=1e-3)
+
+
 def test_oracle_multi_iteration_descends():
     p, plan, hp, _ = load_case("chig")
     pos = fragment_positions(plan, p.positions).astype(np.float32)

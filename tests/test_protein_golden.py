@@ -1,0 +1,42 @@
+"""CPU: the oracle restatement (oracle/visnet_oracle.py) reproduces the reference-source goldens of the real
+protein fragment batches at the benchmarked size (H=256, L=9; oracle/make_protein_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle.visnet_oracle import ViSNetOracle
+from oracle.weights import make_state_dict
+
+
+@pytest.mark.parametrize("name,tag", [("chig", "relaxed"), ("trpcage", "placed")])
+def test_oracle_matches_reference_on_protein_batches(name, tag):
+    d = np.load(os.path.join(GOLDEN, f"visnet_prot_{name}.npz"))
+    hp = json.loads(str(d["hparams"]))
+    sd = make_state_dict(hp, seed=int(d["weight_seed"]))
+    E, F, c = ViSNetOracle(hp, sd, torch.float64).energy_forces(d["z"], d[f"pos_{tag}"], d["start"], d["end"])
+    assert np.diff(c["graph"]["rowptr"]).max() == int(d[f"max_degree_{tag}"]) <= hp["max_num_neighbors"]
+    np.testing.assert_allclose(E, d[f"E_ref64_{tag}"], rtol=0, atol=1e-9 * max(1.0, np.abs(d[f"E_ref64_{tag}"]).max()))
+    np.testing.assert_allclose(F, d[f"F_ref64_{tag}"], rtol=0, atol=1e-9 * max(1.0, np.abs(d[f"F_ref64_{tag}"]).max()))
+
+
+@pytest.mark.parametrize("name", ["chig", "trpcage", "ww", "abd"])
+def test_protein_golden_is_consistent_with_the_plan(name):
+    from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, combine_host, fragment_positions
+
+    d = np.load(os.path.join(GOLDEN, f"visnet_prot_{name}.npz"))
+    z = np.load(os.path.join(GOLDEN, f"protein_{name}.npz"))
+    p = ProteinAtoms(z["names"], z["resnames"], z["resnums"], z["numbers"], z["positions"].astype(np.float64))
+    plan = build_plan(p)
+    assert (plan.z == d["z"]).all() and (plan.start == d["start"]).all() and (plan.end == d["end"]).all()
+    assert np.array_equal(fragment_positions(plan, p.positions).astype(np.float32), d["pos_placed"])
+    for tag in ("relaxed", "placed"):
+        E, F = combine_host(plan, d[f"E_ref64_{tag}"], d[f"F_ref64_{tag}"])
+        assert abs(E - float(d[f"Eprot64_{tag}"])) < 1e-9 and np.abs(F - d[f"Fprot64_{tag}"]).max() < 1e-12
+        # E depends on position differences only: the forces of every fragment sum to zero (the recombined protein
+        # forces do not - the cap hydrogens' rows are dropped by select_index, combiner.py:38)
+        for a, b in zip(d["start"], d["end"]):
+            assert np.abs(d[f"F_ref64_{tag}"][a:b].sum(0)).max() < 1e-9
