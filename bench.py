@@ -1,30 +1,36 @@
 #!/usr/bin/env python
-"""bench.py - MD steps/s on Chignolin through the MI355X ViSNet force path.
+"""bench.py - MD steps/s on Chignolin (+ fragment-batch forces/s) through the MI355X ViSNet force path.
 
-    python bench.py --gpus N --steps K --warmup W [--workload chig_md|frag_batch|ww_md|trpcage_md]
+    python bench.py --gpus N --steps K --warmup W [--workload chig_md|trpcage_md|ww_md|abd_md|frag_batch]
 
-One "step" of the default workload (BASELINE.json configs[1]) = one MD step of
-capped Chignolin (175 atoms -> 19 fragments, 391 fragment atoms): fragment
-gather + cap-hydrogen placement, ViSNet energy+forces of the fragment batch
-(neighbour list, embeddings, 9 ViS-MP layers, read-out, hand-written reverse
-pass), overlap-force recombination, one Langevin update.  Everything stays in
-HBM during the timed region.  With N > 1 (one process per GPU, launched by
-torch.distributed.run) the fragments are sharded over the ranks and one fused
-RCCL all-gather per step recombines shard forces/energies (strong scaling).
-`--workload frag_batch` measures pure fragment-batch force throughput instead
-(independent units, no collective, weak scaling).
+One "step" of the default workload (BASELINE.json configs[1]) = one MD step of capped Chignolin (175 atoms -> 19
+fragments, 391 fragment atoms): fragment gather + cap-hydrogen placement and L-BFGS relaxation, ViSNet
+energy+forces of the fragment batch (neighbour list, embeddings, 9 ViS-MP layers, read-out, hand-written reverse
+pass), overlap-force recombination, one Langevin update.  Everything stays in HBM during the timed region.
 
-Weights are seeded random at the reference's default hyper-parameters (the
-checkpoints are not in the reference tree); the input geometry is the reference's
-own Chignolin example, shipped as tests/golden/protein_chig.npz.
+The ONE JSON line (rank 0) carries the whole BASELINE metric: `value` = Chignolin MD steps/s, and `secondary` =
+fragment-batch forces/s at 4096 fragments per GPU (independent units, no collective, weak scaling), Trp-cage MD
+steps/s (configs[2]) and, for N > 1, WW-domain MD steps/s (configs[3]); each with its own roofline block.
 
-Prints ONE JSON line (rank 0).
+With N > 1 the fragments of the MD workloads are sharded over the ranks (one process per GPU) and one fused RCCL
+all-gather per step recombines shard forces/energies (strong scaling).  `python bench.py --gpus N` starts its own
+ranks (re-executes itself under torch.distributed.run) when it was not launched by one.
+
+Before any clock starts, the forces of the workload's step-0 fragment batch are compared with golden vectors
+computed by the reference's own ViSNet source (tests/golden/visnet_prot_*.npz); a mismatch aborts the run
+(`parity` block).  The timed region lasts at least --min-seconds (steps = max(K, ceil(min_seconds / step))).
+
+Weights are seeded random at the reference's default hyper-parameters (the checkpoints are not in the reference
+tree); the input geometry is the reference's own examples, shipped as tests/golden/protein_*.npz.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,15 +39,137 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_pmc_traffic.json")
+PRETTY = dict(chig="Chignolin", trpcage="Trp-cage", ww="WW domain", abd="ABD")
 
 
+# ------------------------------------------------------------------------------------------------------------
+# launch plumbing
+# ------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="chig_md", choices=["chig_md", "trpcage_md", "ww_md", "abd_md",
+                                                               "frag_batch"])
+    ap.add_argument("--frags-per-gpu", type=int, default=4096)
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="lower bound on the timed region: steps = max(--steps, ceil(min_seconds / step time))")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="primary workload only (profiling runs)")
+    ap.add_argument("--integrator", default="hip", choices=["hip", "torch"],
+                    help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
+    ap.add_argument("--no-relax-caps", action="store_true",
+                    help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
+    ap.add_argument("--mm", action="store_true",
+                    help="add the MM non-bonded term (reference: MMNonBondedCalculator on top of the fragment forces; "
+                         "< 1 %% of the step).  Off by default: with seeded random ViSNet weights nothing but the "
+                         "tether holds polar hydrogens (AMBER gives them no LJ core), so over thousands of steps the "
+                         "Coulomb term tears the structure apart and the workload would change under the clock")
+    ap.add_argument("--emulate-shard", default="", help="tuning aid, single process: 'r/w' = time rank r's share of a "
+                    "w-rank MD job without the collective (not a valid bench line)")
+    ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
+    ap.add_argument("--stub", action="store_true",
+                    help="launch-logic self-test on CPU (gloo, sleep-based fake step): NOT a measurement")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks, one per GPU, like the reference starts its
+    extra GPU workers itself (/root/reference/src/Calculators/visnet_calculator.py:78-118, bonded.py:75-77)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+class Ctx:
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.stub = args.stub
+        self.group = None
+        self.backend = None
+        if self.stub:
+            self.dev = "cpu"
+        else:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = f"cuda:{self.local_rank}"
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend = "gloo" if self.stub else "nccl"  # "nccl" IS RCCL on ROCm
+            kw = {} if self.stub else dict(device_id=torch.device(self.dev))
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        if not self.stub:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], device=self.dev, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def timed_region(ctx, step_fn, steps, warmup, min_seconds):
+    """W untimed warm-up steps, a short calibration, then EXACTLY `k` timed steps bracketed by barrier + device
+    synchronisation on both sides; k = max(steps, ceil(min_seconds / step time)), agreed over the ranks.
+    -> (k, seconds = max over ranks)."""
+    for _ in range(warmup):
+        step_fn()
+    ctx.barrier()
+    ncal = max(1, min(steps, 5))
+    t0 = time.perf_counter()
+    for _ in range(ncal):
+        step_fn()
+    ctx.barrier()
+    est = ctx.max_over_ranks((time.perf_counter() - t0) / ncal)
+    k = int(max(steps, math.ceil(min_seconds / max(est, 1e-9))))
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step_fn()
+    ctx.barrier()
+    return k, ctx.max_over_ranks(time.perf_counter() - t0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# workload helpers
+# ------------------------------------------------------------------------------------------------------------
 def load_protein(name):
     from ai2bmd_amd.fragmentation import ProteinAtoms
 
-    d = np.load(os.path.join(ROOT, "tests", "golden", f"protein_{name}.npz"))
+    d = np.load(os.path.join(GOLD, f"protein_{name}.npz"))
     return ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+
+
+def load_golden(name):
+    d = np.load(os.path.join(GOLD, f"visnet_prot_{name}.npz"))
+    return {k: d[k] for k in d.files}
 
 
 def fwd_flops(N, E, H, L, S, R):
@@ -53,11 +181,247 @@ def fwd_flops(N, E, H, L, S, R):
     return full - (10 * S * N * H * H + 2 * E * H * H if L > 1 else 6 * S * N * H * H)
 
 
+def count_edges(pos, start, end, cutoff, max_nb):
+    """host count of the radius-graph edges (self loops included, <= max_nb sources per target)"""
+    tot = 0
+    for a, b in zip(start, end):
+        p = np.asarray(pos[a:b], np.float32)
+        if len(p):
+            d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+            tot += int(np.minimum((d2 < np.float32(cutoff * cutoff)).sum(1), max_nb).sum())
+    return tot
+
+
+def parity_check(what, E, F, E64, F64, tol_f=1e-4, tol_e=1e-5):
+    """SURVEY.md 8c tolerance (fp32 contract vs the reference's fp64 result); aborts the run on mismatch."""
+    E, F = np.asarray(E, np.float64).reshape(-1), np.asarray(F, np.float64)
+    E64, F64 = np.asarray(E64, np.float64).reshape(-1), np.asarray(F64, np.float64)
+    ok = E.shape == E64.shape and F.shape == F64.shape and np.isfinite(E).all() and np.isfinite(F).all()
+    de = float(np.abs(E - E64).max()) if ok else float("nan")
+    df = float(np.abs(F - F64).max()) if ok else float("nan")
+    mae = float(np.abs(F - F64).mean()) if ok else float("nan")
+    ok = ok and (np.abs(E - E64) <= tol_e * np.maximum(1.0, np.abs(E64))).all() \
+        and df <= tol_f * max(1.0, float(np.abs(F64).max())) and mae <= 0.1 * tol_f * max(1.0, float(np.abs(F64).mean()))
+    if not ok:
+        raise SystemExit(f"PARITY FAILURE before the timed region ({what}): max|dE|={de:.3e} max|dF|={df:.3e} "
+                         f"MAE={mae:.3e} against the reference-source golden - refusing to print a bench line")
+    return dict(max_dE=de, max_dF=df, force_mae=mae, max_abs_F=float(np.abs(F64).max()))
+
+
+def traffic_from_profile(workload, kernel):
+    """HBM traffic per launch of `kernel`: PMC counters need their own rocprofv3 passes, so the per-launch average
+    of the committed run of THIS command is read back from profiles/ (null when absent)."""
+    try:
+        with open(os.path.join(ROOT, TRAFFIC_PROFILE)) as fh:
+            return json.load(fh).get(workload, {}).get(kernel)
+    except Exception:
+        return None
+
+
+def roofline_block(eng, nprof, workload, flops_step, ms_per_step):
+    """Dominant GEMM kernel from the instrumented pass: HIP events on the launch stream around every launch,
+    minus the measured cost of an empty event bracket."""
+    prof = eng.profile_read()
+    br_ms = eng.profile_bracket_ms()
+    dom = max(prof, key=lambda k: prof[k]["ms"])
+    pd = prof[dom]
+    n = max(pd["launches"], 1)
+    raw_us = 1e3 * pd["ms"] / n
+    net_us = max(raw_us - 1e3 * br_ms, 1e-3)
+    ach = (pd["flops"] / n) / (net_us * 1e-6) / 1e12
+    all_ms = sum(v["ms"] - v["launches"] * br_ms for v in prof.values())
+    return dict(
+        bound="mfma", kernel=f"vsn::{dom}", achieved=ach, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+        frac=ach / MFMA_F32_PEAK_TFLOPS,
+        traffic=traffic_from_profile(workload, dom), traffic_source=f"{TRAFFIC_PROFILE} (rocprofv3 PMC passes of this "
+        "command, per launch; not re-measured in this run)",
+        launches_per_step=pd["launches"] / nprof, avg_launch_us=net_us, avg_launch_us_with_event_bracket=raw_us,
+        event_bracket_us=1e3 * br_ms,
+        algorithmic_flop_per_launch=pd["flops"] / n, algorithmic_bytes_per_launch=pd["bytes"] / n,
+        all_gemm_ms_per_step=all_ms / nprof,
+        all_gemm_tflops=(sum(v["flops"] for v in prof.values()) / max(all_ms, 1e-9)) / 1e9,
+        # whole step against the same peak: algorithmic FLOPs of one evaluation / wall time of one step
+        step_frac=(flops_step / (ms_per_step * 1e-3)) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+        step_tflops=(flops_step / (ms_per_step * 1e-3)) / 1e12,
+    )
+
+
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+def run_md(ctx, eng, hp, pname, args, steps, warmup):
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+    from ai2bmd_amd.fragmentation import build_plan, fragment_positions
+    from ai2bmd_amd.md import Langevin, LangevinHIP
+
+    dev = ctx.dev
+    H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
+    prot = load_protein(pname)
+    plan = build_plan(prot)
+    gold = load_golden(pname)
+    hplan = None
+    if not args.no_relax_caps:
+        from ai2bmd_amd.amber import load_tables
+        from ai2bmd_amd.hydrogen import build_hydrogen_plan
+
+        hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    # ---- parity guard 1: the engine on the golden's own fragment batch (same inputs as the reference run) ----
+    tag = "relaxed"
+    z_t = torch.as_tensor(gold["z"], dtype=torch.int64).to(dev)
+    p_t = torch.as_tensor(gold[f"pos_{tag}"], dtype=torch.float32).to(dev)
+    e_t = torch.empty(len(gold["start"]), device=dev)
+    f_t = torch.empty(len(gold["z"]), 3, device=dev)
+    eng.forces_device(z_t, p_t, gold["start"], gold["end"], e_t, f_t)
+    torch.cuda.synchronize()
+    nonempty = (gold["end"] - gold["start"]) > 0
+    par = parity_check(f"{pname} fragment batch, H={H} L={L}", e_t.cpu().numpy()[nonempty], f_t.cpu().numpy(),
+                       gold[f"E_ref64_{tag}"], gold[f"F_ref64_{tag}"])
+    if args.emulate_shard:
+        er, ew = (int(v) for v in args.emulate_shard.split("/"))
+        ff = ShardedFragmentForces.for_engine(eng, plan, rank=er, world=ew, hydrogen=hplan)
+        ff.emulate = True
+    else:
+        ff = ShardedFragmentForces.for_engine(eng, plan, rank=ctx.rank, world=ctx.world, group=ctx.group,
+                                              hydrogen=hplan)
+    # ---- parity guard 2: the device pipeline (gather + cap-H + ViSNet shard + all-gather + combine) at step 0 ----
+    if not args.emulate_shard:
+        x0 = torch.as_tensor(prot.positions, dtype=torch.float32, device=dev)
+        E0, F0 = ff.step(x0)
+        torch.cuda.synchronize()
+        ptag = "relaxed" if hplan is not None else "placed"
+        # the fp32 L-BFGS on the device leaves the cap hydrogens within 2e-4 A of the reference optimiser's
+        pp = parity_check(f"{pname} protein forces after recombination", [float(E0)], F0.cpu().numpy(),
+                          [float(gold[f"Eprot64_{ptag}"])], gold[f"Fprot64_{ptag}"],
+                          tol_f=1e-3 if hplan is not None else 1e-4, tol_e=1e-3)
+        par.update(pipeline_max_dF=pp["max_dF"], pipeline_dE=pp["max_dE"])
+    par["max_dF_over_ranks"] = ctx.max_over_ranks(par["max_dF"])
+    force_fn = ff.step
+    if args.mm:
+        # full AI2BMD potential = fragment (ViSNet) forces + MM Lennard-Jones/Coulomb between atoms that never
+        # share a dipeptide (Calculators/nonbonded.py:33-63); charges / sigma / epsilon from the AMBER tables
+        from types import SimpleNamespace
+
+        from ai2bmd_amd.amber import load_tables, protein_mm_parameters
+        from ai2bmd_amd.nonbonded import MMNonBondedCalculator
+
+        q_, s_, e_ = protein_mm_parameters(prot, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+        mm = MMNonBondedCalculator(dev)
+        mm.set_parameters(SimpleNamespace(charges=q_, sigmas=s_, epsilons=e_), plan)
+
+        def force_fn(pos):
+            E, F = ff.step(pos)
+            e_mm, _ = mm.forces_device(pos, f_out=F, accumulate=True)
+            return E + e_mm[0], F
+
+    Integ = LangevinHIP if args.integrator == "hip" else Langevin
+    md = Integ(prot.numbers, prot.positions, force_fn, dev, seed=0, tether_k=5.0)
+    for _ in range(min(warmup, 3)):
+        md.step()
+    edges_before = eng.last_num_edges()
+    k, el = timed_region(ctx, md.step, steps, max(warmup - 3, 0), args.min_seconds)
+    edges_after = eng.last_num_edges()
+    # the workload must not change under the clock (a structure that flies apart has fewer edges = less work)
+    assert abs(edges_after - edges_before) <= 0.1 * max(edges_before, 1), (edges_before, edges_after)
+    assert torch.isfinite(md.x).all() and torch.isfinite(md.F).all(), "non-finite MD state"
+    ms = 1e3 * el / k
+    n_loc = ff.local_rows
+    # ---- instrumented pass: HIP events around every GEMM launch (same stream) ----
+    eng.set_option("profile", 1)
+    nprof = 5
+    for _ in range(nprof):
+        md.step()
+    torch.cuda.synchronize()
+    flops_step = 2.0 * fwd_flops(n_loc, edges_after, H, L, S, R)
+    roof = roofline_block(eng, nprof, f"{pname}_md", flops_step, ms)
+    eng.set_option("profile", 0)
+    workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
+                f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
+                f"{'+ MM non-bonded (LJ + Coulomb, AMBER parameters), ' if args.mm else ''}Langevin 1 fs 300 K "
+                f"friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
+                f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
+    res = dict(metric=f"MD steps/sec on {PRETTY[pname]}", value=k / el, unit="steps/s", steps=k, ms_per_step=ms,
+               scaling="strong", config=dict(workload=workload, edges_local=edges_after,
+                                             edges_at_start_of_timed_region=edges_before, frag_atoms_local=n_loc,
+                                             algorithmic_gflop_per_step_local=flops_step / 1e9),
+               parity=par, roofline=roof)
+    return res, (plan, prot, md)
+
+
+def run_frag_batch(ctx, eng, hp, args, steps, warmup):
+    """pure fragment-batch force throughput: the per-GPU batch cycles through the 220 fragments of the four example
+    proteins; the first pass keeps the golden geometry (parity guard), later passes add 0.05 A of jitter."""
+    from ai2bmd_amd.fragmentation import build_plan
+
+    dev = ctx.dev
+    H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
+    rng = np.random.default_rng(1234 + ctx.rank)
+    pool, ref_e, ref_f = [], [], []
+    for pname in ("chig", "trpcage", "ww", "abd"):
+        g = load_golden(pname)
+        ib = 0
+        for b in range(len(g["start"])):
+            a0, a1 = int(g["start"][b]), int(g["end"][b])
+            if a1 == a0:
+                continue
+            pool.append((g["z"][a0:a1], g["pos_placed"][a0:a1]))
+            ref_e.append(g["E_ref64_placed"][ib])
+            ref_f.append(g["F_ref64_placed"][a0:a1])
+            ib += 1
+    zs, ps, sizes = [], [], []
+    for i in range(args.frags_per_gpu):
+        zf, pf = pool[i % len(pool)]
+        zs.append(zf)
+        ps.append(pf if i < len(pool) else pf - pf.mean(0) + rng.normal(0, 0.05, size=pf.shape))
+        sizes.append(len(zf))
+    end = np.cumsum(sizes)
+    start = end - np.asarray(sizes)
+    pos_h = np.concatenate(ps).astype(np.float32)
+    z = torch.as_tensor(np.concatenate(zs), dtype=torch.int64).to(dev)
+    pos = torch.as_tensor(pos_h).to(dev)
+    e = torch.empty(len(start), device=dev)
+    f = torch.empty(len(z), 3, device=dev)
+    eng.forces_device(z, pos, start, end, e, f)
+    torch.cuda.synchronize()
+    ng = min(len(pool), args.frags_per_gpu)
+    par = parity_check(f"fragment batch of {args.frags_per_gpu}, first {ng} fragments", e.cpu().numpy()[:ng],
+                       f.cpu().numpy()[: int(end[ng - 1])], np.concatenate(ref_e[:ng]), np.concatenate(ref_f[:ng]))
+    par["max_dF_over_ranks"] = ctx.max_over_ranks(par["max_dF"])
+
+    def step():
+        eng.forces_device(z, pos, start, end, e, f)
+
+    k, el = timed_region(ctx, step, steps, warmup, args.min_seconds)
+    assert torch.isfinite(f).all()
+    ms = 1e3 * el / k
+    E_tot = count_edges(pos_h, start, end, hp["cutoff"], hp["max_num_neighbors"])
+    flops_step = 2.0 * fwd_flops(len(z), E_tot, H, L, S, R)
+    eng.set_option("profile", 1)
+    nprof = 2
+    for _ in range(nprof):
+        step()
+    torch.cuda.synchronize()
+    roof = roofline_block(eng, nprof, "frag_batch", flops_step, ms)
+    eng.set_option("profile", 0)
+    workload = (f"dipeptide/ACE-NME batch: {args.frags_per_gpu} fragments per GPU ({len(z)} atoms, {E_tot} edges) "
+                f"harvested from the example proteins, 0.05 A jitter after the first pass, pure energy+force "
+                f"evaluation, ViSNet H={H} L={L}")
+    return dict(metric="fragment-batch forces/sec", value=k * args.frags_per_gpu * ctx.world / el,
+                unit="fragments/s", steps=k, ms_per_step=ms, scaling="weak",
+                config=dict(workload=workload, atoms_per_gpu=int(len(z)), edges_per_gpu=E_tot,
+                            algorithmic_gflop_per_step_local=flops_step / 1e9),
+                parity=par, roofline=roof)
+
+
 def cpu_baseline_md(plan, prot, hp, sd, budget_s=20.0):
-    """Oracle ("port" of the reference algorithm, plain torch fp32 + autograd) timed on the host cores on
-    the same Chignolin fragment batch - force evaluation only.  torch's intra-op threading saturates
-    early on these small tensors (2x EPYC 9575F: 16 threads 2.4 s, 128 threads 10 s per evaluation), so
-    the thread count is probed and the fastest one is used and reported as `cores`."""
+    """Oracle ("port" of the reference algorithm, plain torch fp32 + autograd) timed on the host cores on the same
+    Chignolin fragment batch - force evaluation only.  Two layouts: (i) ONE partition with the fastest of 8/16/32
+    intra-op threads (torch's intra-op threading saturates early on these small tensors: 2x EPYC 9575F, 16 threads
+    2.4 s, 128 threads 10 s per evaluation); (ii) the reference's own CPU layout - two partitions evaluated by two
+    Python threads on one shared model (device_strategy.py:176,252-263).  `value` = the faster, `cores` = the
+    threads that run actually used."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ai2bmd_amd.device_strategy import device_ranges
     from ai2bmd_amd.fragmentation import fragment_positions
     from oracle.visnet_oracle import ViSNetOracle
 
@@ -79,261 +443,131 @@ def cpu_baseline_md(plan, prot, hp, sd, budget_s=20.0):
         o.energy_forces(plan.z, pos, plan.start, plan.end)
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 8:
+        if el > budget_s / 2 or n >= 6:
             break
-    return dict(value=n / el, unit="MD steps/s", cores=best_nt, kind="port",
-                sample=f"{n} energy+force evaluations of the Chignolin fragment batch (B={len(plan.start)}, "
-                       f"N={len(plan.z)}) by oracle/visnet_oracle.py (fp32 torch + autograd, best of 8/16/32 "
-                       f"intra-op threads on a {ncpu}-hardware-thread host), integrator excluded")
+    single = n / el
+    # (ii) two partitions, two threads (the reference's gpu_count == 0 layout)
+    parts = []
+    for f0, f1 in device_ranges(plan.start, plan.end, 2):
+        a0, a1 = int(plan.start[f0]), int(plan.end[f1 - 1])
+        parts.append((plan.z[a0:a1], pos[a0:a1], plan.start[f0:f1] - a0, plan.end[f0:f1] - a0))
+    nt2 = max(1, best_nt // 2)
+    torch.set_num_threads(nt2)
+
+    def both():
+        with ThreadPoolExecutor(2) as ex:
+            list(ex.map(lambda p_: o.energy_forces(*p_), parts))
+
+    both()
+    n2, t0 = 0, time.perf_counter()
+    while True:
+        both()
+        n2 += 1
+        el2 = time.perf_counter() - t0
+        if el2 > budget_s / 2 or n2 >= 6:
+            break
+    two = n2 / el2
+    use_two = two > single
+    return dict(value=max(single, two), unit="MD steps/s", cores=(2 * nt2 if use_two else best_nt), kind="port",
+                host_hw_threads=ncpu, single_partition_steps_per_s=single, two_partition_steps_per_s=two,
+                sample=f"{n} + {n2} energy+force evaluations of the Chignolin fragment batch (B={len(plan.start)}, "
+                       f"N={len(plan.z)}) by oracle/visnet_oracle.py (fp32 torch + autograd): one partition at "
+                       f"{best_nt} intra-op threads (best of 8/16/32) and the reference's two-partition/two-thread "
+                       f"CPU layout at 2x{nt2} threads, on a {ncpu}-hardware-thread host; integrator excluded")
 
 
+def run_stub(ctx, args):
+    """launch-logic self-test (tests/test_capi_and_host.py): every rank 'steps' by sleeping; exercises the self
+    launch, the barrier / max-over-ranks timing and the one-line report without a GPU."""
+    def step():
+        time.sleep(0.002 * (1 + ctx.rank))
+
+    k, el = timed_region(ctx, step, args.steps, args.warmup, min(args.min_seconds, 0.05))
+    return dict(metric="stub", value=k / el, unit="steps/s", steps=k, ms_per_step=1e3 * el / k, scaling="strong",
+                config=dict(workload="STUB: sleep-based fake step on CPU over gloo - launch-logic test, NOT a measurement"))
+
+
+# ------------------------------------------------------------------------------------------------------------
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="chig_md", choices=["chig_md", "trpcage_md", "ww_md", "abd_md",
-                                                               "frag_batch"])
-    ap.add_argument("--frags-per-gpu", type=int, default=1024)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--integrator", default="hip", choices=["hip", "torch"],
-                    help="Langevin update: two HIP launches per step (default) or ~25 torch elementwise kernels")
-    ap.add_argument("--no-relax-caps", action="store_true",
-                    help="skip the per-step cap-hydrogen L-BFGS relaxation (reference: DistanceFragment.get_fragments)")
-    ap.add_argument("--mm", action="store_true",
-                    help="add the MM non-bonded term (reference: MMNonBondedCalculator on top of the fragment forces; "
-                         "< 1 %% of the step).  Off by default: with seeded random ViSNet weights nothing but the "
-                         "tether holds polar hydrogens (AMBER gives them no LJ core), so over thousands of steps the "
-                         "Coulomb term tears the structure apart and the workload would change under the clock")
-    ap.add_argument("--emulate-shard", default="", help="tuning aid, single process: 'r/w' = time rank r's share of a "
-                    "w-rank MD job without the collective (not a valid bench line)")
-    ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    group = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
-
-    from ai2bmd_amd.bonded import ShardedFragmentForces
-    from ai2bmd_amd.fragmentation import build_plan, fragment_positions
-    from ai2bmd_amd.md import Langevin, LangevinHIP
-    from ai2bmd_amd.visnet_calculator import ViSNetEngine
-    from ai2bmd_amd.synthetic import default_hparams, make_state_dict  # seeded weight generator
-
-    hp = default_hparams()
-    sd = make_state_dict(hp, seed=2024)
-    eng = ViSNetEngine(hp, sd, dev)
-    if args.chunk_edges:
-        eng.set_option("max_chunk_edges", args.chunk_edges)
-    for kv in filter(None, os.environ.get("VSN_OPTS", "").split(",")):  # tuning aid: VSN_OPTS=fuse_fwd=0,overlap=0
-        k_, v_ = kv.split("=")
-        eng.set_option(k_, int(v_))
-    H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    out = {}
-    if args.workload.endswith("_md"):
-        pname = args.workload[:-3]
-        prot = load_protein(pname)
-        plan = build_plan(prot)
-        hplan = None
-        if not args.no_relax_caps:
-            from ai2bmd_amd.amber import load_tables
-            from ai2bmd_amd.hydrogen import build_hydrogen_plan
-
-            hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(ROOT, "tests", "golden",
-                                                                             "amber_tables.npz")))
-        if args.emulate_shard:
-            er, ew = (int(v) for v in args.emulate_shard.split("/"))
-            ff = ShardedFragmentForces.for_engine(eng, plan, rank=er, world=ew, hydrogen=hplan)
-            ff.emulate = True
-        else:
-            ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, group=group, hydrogen=hplan)
-        force_fn = ff.step
-        if args.mm:
-            # full AI2BMD potential = fragment (ViSNet) forces + MM Lennard-Jones/Coulomb between atoms that never
-            # share a dipeptide (Calculators/nonbonded.py:33-63); charges / sigma / epsilon from the AMBER tables
-            from types import SimpleNamespace
-
-            from ai2bmd_amd.amber import load_tables, protein_mm_parameters
-            from ai2bmd_amd.nonbonded import MMNonBondedCalculator
-
-            q_, s_, e_ = protein_mm_parameters(prot, load_tables(os.path.join(ROOT, "tests", "golden",
-                                                                                "amber_tables.npz")))
-            mm = MMNonBondedCalculator(dev)
-            mm.set_parameters(SimpleNamespace(charges=q_, sigmas=s_, epsilons=e_), plan)
-
-            def force_fn(pos):
-                E, F = ff.step(pos)
-                e_mm, _ = mm.forces_device(pos, f_out=F, accumulate=True)
-                return E + e_mm[0], F
-
-        Integ = LangevinHIP if args.integrator == "hip" else Langevin
-        md = Integ(prot.numbers, prot.positions, force_fn, dev, seed=0, tether_k=5.0)
-        for _ in range(args.warmup):
-            md.step()
-        edges_before = eng.last_num_edges()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            md.step()
-        barrier()
-        el = time.perf_counter() - t0
-        edges_after = eng.last_num_edges()
-        # the workload must not change under the clock (a structure that flies apart has fewer edges = less work)
-        assert abs(edges_after - edges_before) <= 0.1 * max(edges_before, 1), (edges_before, edges_after)
-        if world > 1:
-            import torch.distributed as dist
-
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        assert torch.isfinite(md.x).all() and torch.isfinite(md.F).all(), "non-finite MD state"
-        value, unit, metric = args.steps / el, "steps/s", f"MD steps/sec on {pname}"
-        E_edges = eng.last_num_edges()
-        n_loc = ff.local_rows
-        workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
-                    f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
-                    f"{'+ MM non-bonded (LJ + Coulomb, AMBER parameters), ' if args.mm else ''}Langevin 1 fs 300 K "
-                    f"friction 0.001/fs, harmonic tether 5 eV/A^2 (random weights), "
-                    f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
-        scaling = "strong"
-        units_per_step = 1
-        # ---- instrumented pass: HIP events around every GEMM launch (same stream) ----
-        eng.set_option("profile", 1)
-        nprof = 5
-        for _ in range(nprof):
-            md.step()
-        torch.cuda.synchronize()
-        prof = eng.profile_read()
-        eng.set_option("profile", 0)
-        flops_eval = 2.0 * fwd_flops(n_loc, E_edges, H, L, S, R)
-        extra = dict(edges_local=E_edges, edges_at_start_of_timed_region=edges_before, frag_atoms_local=n_loc, algorithmic_gflop_per_step_local=flops_eval / 1e9)
-        if world == 1:
-            # the reference-shaped seam (host numpy in, host numpy out => H2D + D2H over PCIe every call);
-            # reported for information, never as `value`
-            from ai2bmd_amd.fragment import FragmentData, make_batch_index
-            from ai2bmd_amd.visnet_calculator import ViSNetModel
-
-            seam = ViSNetModel.__new__(ViSNetModel)
-            seam.device, seam.engine, seam.stream = dev, eng, torch.cuda.Stream(device=dev)
-            fpos = fragment_positions(plan, prot.positions).astype(np.float32)
-            fd = FragmentData(plan.z, fpos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
-            for _ in range(5):
-                seam.dl_potential_loader(fd)
-            t1 = time.perf_counter()
-            for _ in range(50):
-                seam.dl_potential_loader(fd)
-            extra["host_seam_evals_per_s_pcie_inclusive"] = 50 / (time.perf_counter() - t1)
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    ctx = Ctx(args)
+    if ctx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
+    secondary = []
+    cpu = None
+    if args.stub:
+        res = run_stub(ctx, args)
+        data = "STUB"
     else:
-        # pure fragment-batch throughput: per-GPU batch built from the example proteins' fragments
-        rng = np.random.default_rng(1234 + rank)
-        zs, ps, sizes = [], [], []
-        pool = []
-        for pname in ("chig", "trpcage", "ww", "abd"):
-            pr = load_protein(pname)
-            pl = build_plan(pr)
-            fp = fragment_positions(pl, pr.positions)
-            for b in range(len(pl.start)):
-                pool.append((pl.z[pl.start[b]:pl.end[b]], fp[pl.start[b]:pl.end[b]]))
-        for i in range(args.frags_per_gpu):
-            zf, pf = pool[i % len(pool)]
-            zs.append(zf)
-            ps.append(pf - pf.mean(0) + rng.normal(0, 0.05, size=pf.shape))
-            sizes.append(len(zf))
-        end = np.cumsum(sizes)
-        start = end - np.asarray(sizes)
-        z = torch.as_tensor(np.concatenate(zs), dtype=torch.int64).to(dev)
-        pos = torch.as_tensor(np.concatenate(ps), dtype=torch.float32).to(dev)
-        e = torch.empty(len(start), device=dev)
-        f = torch.empty(len(z), 3, device=dev)
-        for _ in range(args.warmup):
-            eng.forces_device(z, pos, start, end, e, f)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            eng.forces_device(z, pos, start, end, e, f)
-        barrier()
-        el = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
+        from ai2bmd_amd.synthetic import default_hparams, make_state_dict  # seeded weight generator
+        from ai2bmd_amd.visnet_calculator import ViSNetEngine
 
-            t = torch.tensor([el], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        assert torch.isfinite(f).all()
-        value = args.steps * args.frags_per_gpu * world / el
-        unit, metric = "fragments/s", "fragment-batch forces/sec"
-        E_edges = eng.last_num_edges()
-        workload = (f"synthetic dipeptide/ACE-NME batch: {args.frags_per_gpu} fragments per GPU "
-                    f"({len(z)} atoms) harvested from the example proteins with 0.05 A jitter, pure energy+force "
-                    f"evaluation, ViSNet H={H} L={L}")
-        scaling = "weak"
-        eng.set_option("profile", 1)
-        nprof = 2
-        for _ in range(nprof):
-            eng.forces_device(z, pos, start, end, e, f)
-        torch.cuda.synchronize()
-        prof = eng.profile_read()
-        eng.set_option("profile", 0)
-        extra = dict(atoms_per_gpu=int(len(z)), edges_last_chunk=E_edges)
+        hp = default_hparams()
+        sd = make_state_dict(hp, seed=2024)
+        eng = ViSNetEngine(hp, sd, ctx.dev)
+        if args.chunk_edges:
+            eng.set_option("max_chunk_edges", args.chunk_edges)
+        for kv in filter(None, os.environ.get("VSN_OPTS", "").split(",")):  # tuning aid: VSN_OPTS=fuse_fwd=0,overlap=0
+            k_, v_ = kv.split("=")
+            eng.set_option(k_, int(v_))
+        data = ("synthetic (seeded random weights at the reference's default hyper-parameters; "
+                "geometry = reference examples/*.pdb fixtures)")
+        if args.workload.endswith("_md"):
+            res, (plan, prot, md) = run_md(ctx, eng, hp, args.workload[:-3], args, args.steps, args.warmup)
+            if ctx.world == 1 and not args.emulate_shard:
+                # the reference-shaped seam (host numpy in, host numpy out => H2D + D2H over PCIe every call);
+                # reported for information, never as `value`
+                from ai2bmd_amd.fragment import FragmentData, make_batch_index
+                from ai2bmd_amd.fragmentation import fragment_positions
+                from ai2bmd_amd.visnet_calculator import ViSNetModel
 
-    # dominant kernel = the GEMM tile variant with the most device time
-    dom = max(prof, key=lambda k: prof[k]["ms"])
-    pd = prof[dom]
-    gemm_ms_step = sum(v["ms"] for v in prof.values()) / nprof
-    # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes, so the per-launch
-    # average of the committed run of THIS command is read back from profiles/ (null when absent)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get(args.workload, {}).get(dom)
-    except Exception:
-        traffic = None
-    roof = dict(
-        bound="mfma", kernel=f"vsn::{dom}",
-        achieved=(pd["flops"] / (pd["ms"] * 1e-3)) / 1e12 if pd["ms"] > 0 else 0.0,
-        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
-        frac=((pd["flops"] / (pd["ms"] * 1e-3)) / 1e12 / MFMA_F32_PEAK_TFLOPS) if pd["ms"] > 0 else 0.0,
-        traffic=traffic,
-        launches_per_step=pd["launches"] / nprof,
-        avg_launch_us=1e3 * pd["ms"] / max(pd["launches"], 1),
-        algorithmic_bytes_per_launch=pd["bytes"] / max(pd["launches"], 1),
-        all_gemm_ms_per_step=gemm_ms_step,
-        all_gemm_tflops=(sum(v["flops"] for v in prof.values()) / max(sum(v["ms"] for v in prof.values()), 1e-9)) / 1e9,
-    )
+                seam = ViSNetModel.__new__(ViSNetModel)
+                seam.device, seam.engine, seam.stream = ctx.dev, eng, torch.cuda.Stream(device=ctx.dev)
+                fpos = fragment_positions(plan, prot.positions).astype(np.float32)
+                fd = FragmentData(plan.z, fpos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
+                for _ in range(5):
+                    seam.dl_potential_loader(fd)
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    seam.dl_potential_loader(fd)
+                res["config"]["host_seam_evals_per_s_pcie_inclusive"] = 50 / (time.perf_counter() - t1)
+            if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
+                cpu = cpu_baseline_md(plan, prot, hp, sd)
+            del md
+        else:
+            res = run_frag_batch(ctx, eng, hp, args, args.steps, args.warmup)
+        if not args.no_secondary and not args.emulate_shard and args.workload == "chig_md":
+            # the rest of BASELINE.json's metric in the same line: fragment-batch forces/s (weak scaling, no
+            # collective), Trp-cage (configs[2]) and, sharded over N > 1 GPUs, the WW domain (configs[3])
+            extra_md = ["trpcage"] + (["ww"] if ctx.world > 1 else [])
+            for pname in extra_md:
+                r2, keep = run_md(ctx, eng, hp, pname, args, 50, 10)
+                del keep
+                secondary.append(r2)
+            secondary.append(run_frag_batch(ctx, eng, hp, args, 2, 1))
     out = dict(
-        metric=metric, value=value, unit=unit, n_gpus=world, steps=args.steps, warmup=args.warmup,
-        ms_per_step=1e3 * el / args.steps, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype="f32",
-        data="synthetic (seeded random weights at the reference's default hyper-parameters; "
-             "geometry = reference examples/*.pdb fixtures)",
-        config=dict(workload=workload, **extra), roofline=roof,
+        metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=ctx.world, steps=res["steps"],
+        steps_requested=args.steps, warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True,
+        scaling=res["scaling"], vs_baseline=None, dtype="f32", data=data, config=res["config"],
+        rccl_ranks=ctx.world, backend=ctx.backend or "none (single process)",
     )
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload.endswith("_md"):
-        out["cpu_baseline"] = cpu_baseline_md(plan, prot, hp, sd)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    for key in ("parity", "roofline"):
+        if key in res:
+            out[key] = res[key]
+    if "parity" in res:
+        out["parity_max_dF"] = res["parity"]["max_dF_over_ranks"]
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    if secondary:
+        out["secondary"] = [dict(metric=r["metric"], value=r["value"], unit=r["unit"], n_gpus=ctx.world,
+                                 steps=r["steps"], ms_per_step=r["ms_per_step"], scaling=r["scaling"],
+                                 config=r["config"], parity_max_dF=r["parity"]["max_dF_over_ranks"],
+                                 roofline=r["roofline"]) for r in secondary]
+    if ctx.rank == 0:
+        print(json.dumps(out), flush=True)
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -7,8 +7,8 @@ R=$PWD
 OUT=$R/gpurun_out/${1:-round}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CH="python $R/bench.py --no-cpu-baseline"
-BA="python $R/bench.py --no-cpu-baseline --workload frag_batch --frags-per-gpu 4096"
+CH="python $R/bench.py --no-cpu-baseline --no-secondary --min-seconds 0"
+BA="python $R/bench.py --no-cpu-baseline --no-secondary --min-seconds 0 --workload frag_batch --frags-per-gpu 4096"
 
 timeout 600 rocprofv3 --kernel-trace -d "$OUT/kt_chig" -o c -- $CH --steps 400 --warmup 10 > "$OUT/kt_chig.log" 2>&1
 timeout 600 rocprofv3 --kernel-trace -d "$OUT/kt_batch" -o c -- $BA --steps 2 --warmup 1 > "$OUT/kt_batch.log" 2>&1
