@@ -5,8 +5,9 @@ fragments -> contiguous atom-balanced partitions (device_strategy.py:84-127) -> 
 model per device -> concatenate -> split dipeptide/ACE-NME -> combine
 (combiner.py:12-41).  Two hosts are provided:
 
-* `DLBondedCalculator` - the reference's in-process shape: one Python thread per
-  device handle (bonded.py:75-77), host numpy in/out, same return tuple.  The
+* `DLBondedCalculator` - the reference's in-process shape: same constructor, `calculate`
+  and `__call__(prot)`; one Python thread per device handle (bonded.py:75-77), host numpy
+  in/out, same return tuple.  The
   reference reaches GPUs >= 2 through pickle-over-socket worker processes
   (visnet_calculator.py:78-118); here every device is an in-process handle.
 * `ShardedFragmentForces` - the MI355X-native shape: one process per GPU
@@ -24,18 +25,55 @@ import numpy as np
 import torch
 
 from . import capi
-from .device_strategy import DEFAULT_CHUNK_ATOMS, device_ranges, work_partitions
+from .device_strategy import DEFAULT_CHUNK_ATOMS, DeviceStrategy, device_ranges, work_partitions
 from .fragment import FragmentData
 from .fragmentation import FragmentPlan
 
 
+class DipeptideBondedCombiner:
+    """numpy mirror of Calculators/combiner.py:5-41."""
+
+    @staticmethod
+    def energy_combine(dipeptides_energy, ACE_NMEs_energy):
+        return np.float32(np.asarray(dipeptides_energy).sum() - np.asarray(ACE_NMEs_energy).sum())
+
+    @staticmethod
+    def forces_combine(prot_len, dipeptides_forces, ACE_NMEs_forces, select_index, origin_index):
+        cat = np.concatenate([np.asarray(dipeptides_forces), -np.asarray(ACE_NMEs_forces)])[np.asarray(select_index)]
+        out = np.zeros((prot_len, 3), dtype=np.float32)
+        np.add.at(out, np.asarray(origin_index), cat)
+        return out
+
+
 class DLBondedCalculator:
-    def __init__(self, models, chunk_atoms: int = DEFAULT_CHUNK_ATOMS):
+    r"""Mirror of the reference's DLBondedCalculator (bonded.py:18-123): same constructor
+    (`ckpt_path, ckpt_type`), `calculate(fragments)` and `__call__(prot)`; devices and work partitions come from
+    `DeviceStrategy`, the models from `get_visnet_model` (one in-process handle per 'cuda:k')."""
+
+    def __init__(self, ckpt_path: str, ckpt_type: str, **kwargs) -> None:
+        import os.path as osp
+
+        from .distancefrag import DistanceFragment
+        from .visnet_calculator import get_visnet_model
+
+        self.ckpt_path, self.ckpt_type = ckpt_path, ckpt_type
+        self.fragment_method = DistanceFragment()
+        self.combiner = DipeptideBondedCombiner()
+        model_path = osp.join(self.ckpt_path, f"visnet-uni-{self.ckpt_type}.ckpt")
+        self.models = [get_visnet_model(model_path, device) for device in DeviceStrategy.get_bonded_devices()]
+        self.chunk_atoms = DeviceStrategy._chunk_size
+        self._work = None
+
+    @classmethod
+    def from_models(cls, models, chunk_atoms: int = DEFAULT_CHUNK_ATOMS, fragment_method=None):
+        """test / embedding aid: wrap already constructed model handles (no checkpoint file, no DeviceStrategy)"""
         if not models:
             raise RuntimeError("No compute resources for bonded calculation")
-        self.models = list(models)
-        self.chunk_atoms = chunk_atoms
-        self._work = None
+        self = cls.__new__(cls)
+        self.ckpt_path = self.ckpt_type = None
+        self.fragment_method, self.combiner = fragment_method, DipeptideBondedCombiner()
+        self.models, self.chunk_atoms, self._work = list(models), chunk_atoms, None
+        return self
 
     def set_work_partitions(self, start, end):
         self._work = work_partitions(start, end, len(self.models), self.chunk_atoms)
@@ -47,10 +85,14 @@ class DLBondedCalculator:
 
     def calculate(self, fragments: FragmentData):
         """-> (dipeptides_energy, dipeptides_forces, ACE_NMEs_energy, ACE_NMEs_forces) numpy."""
-        if self._work is None:
-            self.set_work_partitions(fragments.start, fragments.end)
+        work = self._work
+        if work is None:
+            work = DeviceStrategy.get_work_partitions() if self.ckpt_path is not None else None
+            if not work:
+                self.set_work_partitions(fragments.start, fragments.end)
+                work = self._work
         parts = [[] for _ in self.models]
-        for dev, f0, f1 in self._work:
+        for dev, f0, f1 in work:
             if f1 > f0:
                 parts[dev].append(fragments[f0:f1])
         with ThreadPoolExecutor(len(self.models)) as ex:
@@ -61,6 +103,15 @@ class DLBondedCalculator:
         e_dip, e_ace = (energy[s] for s in fragments.scalar_split())
         f_dip, f_ace = (forces[s] for s in fragments.vector_split())
         return e_dip, f_dip, e_ace, f_ace
+
+    def __call__(self, prot):
+        """-> (energy, forces[n_prot,3]) like bonded.py:102-123: fragments of the current positions (cap hydrogens
+        placed and relaxed), model evaluation, recombination with prot.select_index / prot.origin_index."""
+        fragments = self.fragment_method.get_fragments(prot)
+        e_dip, f_dip, e_ace, f_ace = self.calculate(fragments)
+        energy = self.combiner.energy_combine(e_dip, e_ace)
+        forces = self.combiner.forces_combine(len(prot), f_dip, f_ace, prot.select_index, prot.origin_index)
+        return energy, forces
 
 
 def combine_numpy(n_prot, e_dip, f_dip, e_ace, f_ace, select_index, origin_index):

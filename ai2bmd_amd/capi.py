@@ -26,6 +26,9 @@ class VsnHParams(C.Structure):
         ("vecnorm_type", C.c_int32),
         ("has_atomref", C.c_int32),
         ("cutoff", C.c_float),
+        ("rbf_type", C.c_int32),
+        ("activation", C.c_int32),
+        ("attn_activation", C.c_int32),
     ]
 
 
@@ -47,6 +50,8 @@ class VsnHoptTerms(C.Structure):
 
 
 VECNORM = {"none": 0, "rms": 1, "max_min": 2}
+RBF = {"expnorm": 0, "gauss": 1}
+ACTIVATION = {"silu": 0, "swish": 0, "ssp": 1, "tanh": 2, "sigmoid": 3}  # utils.py:93-116 act_class_mapping
 _lib = None
 
 
@@ -118,6 +123,13 @@ def lib() -> C.CDLL:
     L.vsn_md_half1.restype = C.c_int
     L.vsn_md_half2.argtypes = [vp, f32p, f32p, f32p, vp]
     L.vsn_md_half2.restype = C.c_int
+    fp_ = C.POINTER(C.c_float)
+    L.vsn_md_set_restraints.argtypes = [vp, C.c_int64, i64p, fp_, fp_, fp_, C.c_int64, i64p, i64p, fp_, fp_]
+    L.vsn_md_set_restraints.restype = C.c_int
+    L.vsn_md_restrain.argtypes = [vp, f32p, f32p, vp]
+    L.vsn_md_restrain.restype = C.c_int
+    L.vsn_md_observe.argtypes = [vp, f32p, C.c_float, f32p, vp]
+    L.vsn_md_observe.restype = C.c_int
     L.vsn_mm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                 C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.vsn_mm_create.restype = C.c_int
@@ -148,6 +160,6 @@ EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
     "vsn_forces", "vsn_profile_read", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_combine_plan_set_energy", "vsn_combine_with_energy", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
-    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
+    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
     "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",
 ]

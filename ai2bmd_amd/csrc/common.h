@@ -24,12 +24,90 @@ __device__ __forceinline__ void silu_both(float x, float& y, float& dy) {
   dy = s * (1.0f + x * (1.0f - s));
 }
 
+// ---- the reference's activation table (ViSNet/model/utils.py:93-116 act_class_mapping) -----------------
+// kind is a kernel argument (wave-uniform): silu / swish keep their branch-free fast path.
+#define VSN_ACT_SILU 0     // "silu", "swish": x sigmoid(x)
+#define VSN_ACT_SSP 1      // "ssp": softplus(x) - ln 2   (F.softplus: beta 1, linear above 20)
+#define VSN_ACT_TANH 2     // "tanh"
+#define VSN_ACT_SIGMOID 3  // "sigmoid"
+__device__ __forceinline__ void act_both(int kind, float x, float& y, float& dy) {
+  if (kind == VSN_ACT_SILU) {
+    silu_both(x, y, dy);
+  } else if (kind == VSN_ACT_SSP) {
+    const float s = sigmoid_f(x);
+    y = (x > 20.0f ? x : log1pf(expf(x))) - 0.69314718055994531f;
+    dy = x > 20.0f ? 1.0f : s;
+  } else if (kind == VSN_ACT_TANH) {
+    const float t = tanhf(x);
+    y = t;
+    dy = 1.0f - t * t;
+  } else {
+    const float s = sigmoid_f(x);
+    y = s;
+    dy = s * (1.0f - s);
+  }
+}
+__device__ __forceinline__ float act_f(int kind, float x) {
+  if (kind == VSN_ACT_SILU) return silu_f(x);
+  float y, dy;
+  act_both(kind, x, y, dy);
+  return y;
+}
+__device__ __forceinline__ float dact_f(int kind, float x) {
+  if (kind == VSN_ACT_SILU) return dsilu_f(x);
+  float y, dy;
+  act_both(kind, x, y, dy);
+  return dy;
+}
+
 // ---- wave64 reductions -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Multi-value wave reduction: every lane holds P partial sums p[0..P) (P = 4 or 8); returns, in EVERY lane, the
+// total over the 64 lanes of component (lane & (P-1)).  A butterfly that halves the number of live values at each of
+// the first log2(P) steps (a lane keeps the components whose index bit matches its lane bit and ships the others to
+// its partner): P-1 + (6 - log2 P) cross-lane moves instead of 6 P for P separate wave_sum()s; fixed order.
+template <int P>
+__device__ __forceinline__ float wave_multi_sum(const float (&p)[P], int lane) {
+  static_assert(P == 4 || P == 8, "P must be 4 or 8");
+  float v;
+  if constexpr (P == 8) {
+    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float q[4], r[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float keep = b2 ? p[k + 4] : p[k], send = b2 ? p[k] : p[k + 4];
+      q[k] = keep + __shfl_xor(send, 4, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float keep = b1 ? q[k + 2] : q[k], send = b1 ? q[k] : q[k + 2];
+      r[k] = keep + __shfl_xor(send, 2, 64);
+    }
+    const float keep = b0 ? r[1] : r[0], send = b0 ? r[0] : r[1];
+    v = keep + __shfl_xor(send, 1, 64);
+    v += __shfl_xor(v, 8, 64);
+  } else {
+    const bool b1 = lane & 2, b0 = lane & 1;
+    float r[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float keep = b1 ? p[k + 2] : p[k], send = b1 ? p[k] : p[k + 2];
+      r[k] = keep + __shfl_xor(send, 2, 64);
+    }
+    const float keep = b0 ? r[1] : r[0], send = b0 ? r[0] : r[1];
+    v = keep + __shfl_xor(send, 1, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+  }
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
 // sum over aligned groups of `width` consecutive lanes (width power of two)
 __device__ __forceinline__ float group_sum(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -52,22 +130,53 @@ struct RowVec<4> {
   typedef float4 T;
 };
 
+// V in {1, 2, 4}: one 4/8/16-byte access per lane.  Other widths (hidden = 192, 320, 384, 448, 512) split the
+// lane's V contiguous floats into the widest aligned pieces (V = 8: two 16-byte accesses; odd V: dwords).
 template <int V>
 __device__ __forceinline__ void ldrow(const float* __restrict__ row, int lane, float (&r)[V]) {
-  typedef typename RowVec<V>::T T;
-  T t = *reinterpret_cast<const T*>(row + lane * V);
-  const float* p = reinterpret_cast<const float*>(&t);
+  if constexpr (V == 1 || V == 2 || V == 4) {
+    typedef typename RowVec<V>::T T;
+    T t = *reinterpret_cast<const T*>(row + lane * V);
+    const float* p = reinterpret_cast<const float*>(&t);
 #pragma unroll
-  for (int i = 0; i < V; ++i) r[i] = p[i];
+    for (int i = 0; i < V; ++i) r[i] = p[i];
+  } else if constexpr (V % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(row + lane * V + 4 * q);
+      r[4 * q] = t.x, r[4 * q + 1] = t.y, r[4 * q + 2] = t.z, r[4 * q + 3] = t.w;
+    }
+  } else if constexpr (V % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < V / 2; ++q) {
+      const float2 t = *reinterpret_cast<const float2*>(row + lane * V + 2 * q);
+      r[2 * q] = t.x, r[2 * q + 1] = t.y;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = row[lane * V + i];
+  }
 }
 template <int V>
 __device__ __forceinline__ void strow(float* __restrict__ row, int lane, const float (&r)[V]) {
-  typedef typename RowVec<V>::T T;
-  T t;
-  float* p = reinterpret_cast<float*>(&t);
+  if constexpr (V == 1 || V == 2 || V == 4) {
+    typedef typename RowVec<V>::T T;
+    T t;
+    float* p = reinterpret_cast<float*>(&t);
 #pragma unroll
-  for (int i = 0; i < V; ++i) p[i] = r[i];
-  *reinterpret_cast<T*>(row + lane * V) = t;
+    for (int i = 0; i < V; ++i) p[i] = r[i];
+    *reinterpret_cast<T*>(row + lane * V) = t;
+  } else if constexpr (V % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < V / 4; ++q)
+      *reinterpret_cast<float4*>(row + lane * V + 4 * q) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+  } else if constexpr (V % 2 == 0) {
+#pragma unroll
+    for (int q = 0; q < V / 2; ++q) *reinterpret_cast<float2*>(row + lane * V + 2 * q) = make_float2(r[2 * q], r[2 * q + 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) row[lane * V + i] = r[i];
+  }
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -113,7 +222,8 @@ __device__ __forceinline__ int edge_cache_get(int cache, const int* __restrict__
 template <int V, int K, int WPN>
 __device__ __forceinline__ void node_reduce(float (&acc)[K][V], float* __restrict__ smem, int lane, int sub) {
   if (WPN == 1) return;
-  constexpr int KC = K < VSN_REDUCE_ROWS ? K : VSN_REDUCE_ROWS;
+  constexpr int RMAX = (32 / V) < VSN_REDUCE_ROWS ? (32 / V) : VSN_REDUCE_ROWS;  // <= 57 KB of scratch for any V
+  constexpr int KC = K < RMAX ? K : RMAX;
 #pragma unroll
   for (int k0 = 0; k0 < K; k0 += KC) {
     __syncthreads();  // smem may still be read from the previous use

@@ -103,6 +103,7 @@ struct vsn_ctx {
   // more than the 11-16 us forward edge update it hides, so only the reverse pass (50-60 us of side work per layer) forks.
   int overlap = 2;
   bool fuse_fwd = true, fuse_bwd_opt = true;
+  bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -144,7 +145,11 @@ extern "C" int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id)
   c->nh = hp->num_heads;
   c->Z = hp->max_z;
   *out = c;
-  if (!(c->H == 64 || c->H == 128 || c->H == 256)) return fail(c, -22, "hidden must be 64, 128 or 256");
+  if (c->H < 64 || c->H > 512 || (c->H % 64)) return fail(c, -22, "hidden must be a multiple of 64 in [64, 512]");
+  if (hp->rbf_type < 0 || hp->rbf_type > 1) return fail(c, -22, "unknown rbf_type");
+  if (hp->activation < 0 || hp->activation > 3 || hp->attn_activation < 0 || hp->attn_activation > 3)
+    return fail(c, -22, "unknown activation");
+  if (hp->num_rbf < 1) return fail(c, -22, "num_rbf must be >= 1");
   if (!(hp->lmax == 1 || hp->lmax == 2)) return fail(c, -22, "lmax must be 1 or 2");
   if (c->nh <= 0 || c->nh > 64 || (c->nh & (c->nh - 1)) || (c->H % c->nh))
     return fail(c, -22, "num_heads must be a power of two <= 64 dividing hidden");
@@ -206,6 +211,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->fuse_fwd = value != 0;
   } else if (k == "fuse_bwd") {
     c->fuse_bwd_opt = value != 0;
+  } else if (k == "split_rev") {
+    c->split_rev = value != 0;
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -270,8 +277,11 @@ extern "C" int vsn_finalize(vsn_handle c) {
   if (!var) return fail(c, -2, miss);
 
   NEED(emb1, rm + "embedding.weight", (size_t)Z * H);
-  NEED(means, rm + "distance_expansion.means", (size_t)R);
-  NEED(betas, rm + "distance_expansion.betas", (size_t)R);
+  // expnorm: means / betas (utils.py:40-46); gauss: offset [R] and the scalar coeff (utils.py:75-79) ride in the
+  // same two device arrays (means = offset, betas[0] = coeff)
+  const bool gauss = c->hp.rbf_type == 1;
+  NEED(means, rm + (gauss ? "distance_expansion.offset" : "distance_expansion.means"), (size_t)R);
+  NEED(betas, rm + (gauss ? "distance_expansion.coeff" : "distance_expansion.betas"), (size_t)(gauss ? 1 : R));
   NEED(emb2, rm + "neighbor_embedding.embedding.weight", (size_t)Z * H);
   NEED(Wd, rm + "neighbor_embedding.distance_proj.weight", (size_t)H * R);
   NEED(bd, rm + "neighbor_embedding.distance_proj.bias", (size_t)H);
@@ -675,6 +685,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   g.R = c->R;
   g.Rp = Rp;
   g.S = S;
+  g.rbf_type = c->hp.rbf_type;
   g.means = c->means;
   g.betas = c->betas;
   g.deg = c->deg;
@@ -701,6 +712,8 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   D.nh = c->nh;
   D.R = c->R;
   D.Rp = Rp;
+  D.act = c->hp.activation;
+  D.attn_act = c->hp.attn_activation;
   D.ecount = c->ecount;
   D.rowptr = c->rowptr;
   D.colptr = c->colptr;
@@ -843,14 +856,28 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, l0 ? nullptr : c->g_vh, c->g_geo));
     }
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
+    Parts mparts{nullptr, 0, 0}, aparts{nullptr, 0, 0};
+    const bool split_rev = c->split_rev && !c->debug && N < 4096 && Emax < 32768 &&
+                           (size_t)(2 * (size_t)Emax + 3 * (size_t)N) * H <= c->splitk_elems;
     {
       // g_A = g_o.Wo (N rows, tiny) rides along with g_m = g_t.Ws (E rows) in one grouped launch
       GemmDesc gd[2];
       gd[0] = gemm_desc(c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0);
       gd[1] = gemm_desc(c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0);
+      if (split_rev) {
+        // single-protein sizes: these two long-K products give only ~1.75 64x64 tiles per CU (two waves per SIMD,
+        // a latency-bound k-loop).  Cut K into slices of H (uniform 8-k-tile units, ~3.6 per CU) and let the
+        // attention adjoint, which reads both results row by row anyway, add the slices up: no reduction launch.
+        gd[0].keep_parts = 2;
+        gd[0].part = c->splitk;
+        gd[1].keep_parts = 3;
+        gd[1].part = c->splitk + (size_t)2 * Emax * H;
+        mparts = Parts{gd[0].part, (size_t)Emax * H, 2};
+        aparts = Parts{gd[1].part, (size_t)N * H, 3};
+      }
       RC(launch_gemm_group(st, gd, 2));
     }
-    RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo));
+    RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts));
     snapshot(c, st, "g_m", l, c->g_m, (size_t)Emax * H);
     snapshot(c, st, "g_pe", l, c->g_pe, (size_t)Emax * 3 * H);
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);

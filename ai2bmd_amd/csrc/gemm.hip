@@ -20,6 +20,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef VSN_LAB_PRIO
+#define VSN_LAB_PRIO 0  // tools/lab/gemm_direct.hip: s_setprio placement experiments (0 = none, the product build)
+#endif
+
 namespace vsn {
 
 // SILU: apply silu() to A on its way into LDS (one product of the read-out head); a template parameter so that
@@ -58,6 +62,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
   constexpr bool silu_a = SILU;
+  const int akind = flags >> 8;
   // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce)
   const int nkt_all = K / BK;
   const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
@@ -88,11 +93,11 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       const int f_ = tid + it * 256;                                          \
       const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
       f32x4 v_ = ra[it];                                                      \
-      if (silu_a) {                                                           \
-        v_.x = silu_f(v_.x);                                                  \
-        v_.y = silu_f(v_.y);                                                  \
-        v_.z = silu_f(v_.z);                                                  \
-        v_.w = silu_f(v_.w);                                                  \
+      if (silu_a) { /* activation kind (VSN_ACT_*) rides in flags bits 8.. */  \
+        v_.x = act_f(akind, v_.x);                                            \
+        v_.y = act_f(akind, v_.y);                                            \
+        v_.z = act_f(akind, v_.z);                                            \
+        v_.w = act_f(akind, v_.w);                                            \
       }                                                                       \
       *reinterpret_cast<f32x4*>(As_ + r_ * LS + c4_ * 4) = v_;                \
     }                                                                         \
@@ -152,6 +157,9 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     }
     const float* As = smem + (DB ? (kt & 1) : 0) * STAGE;
     const float* Bs = As + BM * LS;
+#if VSN_LAB_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);  // lab: favour waves inside their MFMA block
+#endif
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[MI], b[NI];
@@ -171,6 +179,11 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
+#if VSN_LAB_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#elif VSN_LAB_PRIO == 1
+    __builtin_amdgcn_s_setprio(3);  // lab: favour waves in their LDS-store / prefetch / barrier phase
+#endif
     if (DB && kt + 1 < nkt) {
       // tile kt+1 (in registers) -> the other LDS buffer (last read in iteration kt-1, a barrier ago)
       VSN_SSTORE((kt + 1) & 1);
@@ -179,6 +192,9 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       __builtin_amdgcn_sched_barrier(0);  // issue the prefetch before the barrier / next MFMA block
     }
     __syncthreads();
+#if VSN_LAB_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
   }
 
 #pragma unroll
@@ -390,11 +406,14 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     const GemmDesc& d = descs[i];
     if (d.M <= 0) continue;
     if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) groupable = false;
+    if (d.keep_parts > 1 && (!d.part || (d.K / 32) < d.keep_parts || (d.flags & 1) || d.bias)) return -22;
     if (gemm_variant(d.M, d.Nc) == 0) groupable = false;  // big enough to fill the chip alone
     if (d.flags & 2) groupable = false;                   // silu(A) has its own kernels
     tiles += (long long)((d.M + 63) / 64) * (d.Nc / 64);
   }
   if (!groupable) {
+    for (int i = 0; i < n; ++i)
+      if (descs[i].keep_parts > 1) return -22;  // partial slices are a grouped-launch feature (caller's guard)
     for (int i = 0; i < n; ++i) {
       const GemmDesc& d = descs[i];
       int rc = launch_gemm(st, d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K, d.flags);
@@ -428,19 +447,24 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     if (d.M <= 0) continue;
     const int t = ((d.M + 63) / 64) * (d.Nc / 64);
     int ks = 1;
-    if (tiles < g_splitk_tiles && d.K >= 512 && tl_splitk_ws && (d.ldc & 3) == 0) {
-      ks = (int)((1024 + tiles - 1) / tiles);
-      const int kmax = d.K / 128;
-      if (ks > kmax) ks = kmax;
-      if (ks > 8) ks = 8;
-      while (ks > 1 && ws_off + (size_t)ks * d.M * d.Nc > tl_splitk_elems) --ks;
-      if (ks < 1) ks = 1;
-    }
-    d.ksplit = ks;
-    d.part = ks > 1 ? tl_splitk_ws + ws_off : nullptr;
-    if (ks > 1) {
-      ws_off += (size_t)ks * d.M * d.Nc;
-      red[nred++] = d;
+    if (d.keep_parts > 1) {
+      ks = d.keep_parts;  // slices stay in d.part (caller's buffer); the consumer sums them
+      d.ksplit = ks;
+    } else {
+      if (tiles < g_splitk_tiles && d.K >= 512 && tl_splitk_ws && (d.ldc & 3) == 0) {
+        ks = (int)((1024 + tiles - 1) / tiles);
+        const int kmax = d.K / 128;
+        if (ks > kmax) ks = kmax;
+        if (ks > 8) ks = 8;
+        while (ks > 1 && ws_off + (size_t)ks * d.M * d.Nc > tl_splitk_elems) --ks;
+        if (ks < 1) ks = 1;
+      }
+      d.ksplit = ks;
+      d.part = ks > 1 ? tl_splitk_ws + ws_off : nullptr;
+      if (ks > 1) {
+        ws_off += (size_t)ks * d.M * d.Nc;
+        red[nred++] = d;
+      }
     }
     d.blocks = (t * ks + 7) & ~7;  // multiple of 8: local block id % 8 stays the XCD id
     grid += d.blocks;

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void k_graph_fill_small(const float* __restrict
 // per-edge geometry: one thread per (edge, rbf index); Rp = padded rbf count (multiple of 32)
 __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ tgt,
                             const int* __restrict__ ecount, const float* __restrict__ means,
-                            const float* __restrict__ betas, int R, int Rp, float rc, float alpha, int S,
+                            const float* __restrict__ betas, int rbf_type, int R, int Rp, float rc, float alpha, int S,
                             float* __restrict__ geo /*[E,8]: r,C,dC,ux,uy,uz,rinv,pad*/, float* __restrict__ d,
                             float* __restrict__ rbf, float* __restrict__ drbf) {
   const int E = *ecount;
@@ -234,7 +234,13 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
   float inside = (r < rc) ? 1.f : 0.f;
   float C = 0.5f * (cosf(r * pi_rc) + 1.0f) * inside;
   float dC = -0.5f * pi_rc * sinf(r * pi_rc) * inside;
-  if (k < R) {
+  if (k < R && rbf_type == 1) {
+    // GaussianSmearing (utils.py:60-87): exp(coeff (r - offset_k)^2), NO cutoff factor; means = offset, betas[0] = coeff
+    const float coeff = betas[0], dr = r - means[k];
+    const float ek = expf(coeff * dr * dr);
+    rbf[e * Rp + k] = ek;
+    drbf[e * Rp + k] = 2.0f * coeff * dr * ek;
+  } else if (k < R) {
     float t = expf(-alpha * r);
     float mu = means[k], be = betas[k];
     float ek = expf(-be * (t - mu) * (t - mu));
@@ -361,7 +367,7 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   int blocks = (int)((tot + 255) / 256);
   if (blocks > 0)
     hipLaunchKernelGGL(k_edge_geom, dim3(blocks), dim3(256), 0, st, a.pos, a.src, a.tgt, a.ecount, a.means, a.betas,
-                       a.R, a.Rp, a.rc, a.alpha, a.S, a.geo, a.d, a.rbf, a.drbf);
+                       a.rbf_type, a.R, a.Rp, a.rc, a.alpha, a.S, a.geo, a.d, a.rbf, a.drbf);
   return 0;
 }
 

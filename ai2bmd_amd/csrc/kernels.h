@@ -16,6 +16,7 @@ struct GraphArgs {
   int B, N, Emax, max_frag;
   float rc, rc2, alpha;
   int max_nb, R, Rp, S;
+  int rbf_type;        // 0 expnorm (means, betas), 1 gauss (means = offset, betas[0] = coeff)
   const float* means;
   const float* betas;
   int* deg;
@@ -37,6 +38,7 @@ struct GraphArgs {
 // Everything the per-layer kernels need (one chunk).
 struct Dims {
   int N, Emax, H, S, nh, R, Rp;
+  int act, attn_act;  // VSN_ACT_* of hparams "activation" / "attn_activation" (common.h)
   const int* ecount;
   const int* rowptr;
   const int* colptr;
@@ -56,6 +58,10 @@ struct GemmDesc {
   const int* Mptr;
   float* part;
   int lda, ldb, ldc, M, Nc, K, flags, ksplit, blocks;
+  // keep_parts > 1: cut K into exactly that many slices and LEAVE the partial products in `part`
+  // ([keep_parts][M][Nc], M = the host-side row bound) - no reduction launch; the consumer kernel adds the
+  // slices up in a fixed order while it reads them (grouped launches only)
+  int keep_parts;
 };
 struct GemmGroup {
   static constexpr int MAXP = 4;
@@ -80,6 +86,7 @@ inline GemmDesc gemm_desc(const float* A, int lda, const float* Bt, int ldb, flo
   d.flags = flags;
   d.ksplit = 1;
   d.blocks = 0;
+  d.keep_parts = 0;
   return d;
 }
 
@@ -144,8 +151,16 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
                       float* g_t, float* g_vh, float* g_geo);
 int launch_bwd_vecmsg_S(hipStream_t st, const Dims& D, const float* g_vec, const float* tpre, float* g_vh);
+// K-slices of a product left un-summed by the GEMM (GemmDesc::keep_parts): slice k of row r is p + k * stride + r * ld
+struct Parts {
+  const float* p;
+  size_t stride;
+  int n;  // 0: not split, read the plain array
+};
+// g_m_parts / g_A_parts: when n > 0 the incoming dE/dm rows / dE/dA rows are read as sums of those slices
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
-                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo);
+                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts = Parts{nullptr, 0, 0},
+                    Parts g_A_parts = Parts{nullptr, 0, 0});
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh, const float* xn,
                          const float* rstd, const float* gamma, const float* wvec, int norm_type, int accumulate,
                          float* g_x, float* g_vec);

@@ -26,20 +26,25 @@ namespace vsn {
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
     else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
   } while (0)
+#define VSN_DISPATCH_V(V_, S_, W_, FN, ...)                              \
+  do {                                                                   \
+    if ((S_) == 8) VSN_DISPATCH3(V_, 8, W_, FN, __VA_ARGS__);            \
+    else if ((S_) == 3) VSN_DISPATCH3(V_, 3, W_, FN, __VA_ARGS__);       \
+    else return -22;                                                     \
+  } while (0)
 #define VSN_DISPATCH_VS(H_, S_, W_, FN, ...)                             \
   do {                                                                   \
-    const int v__ = (H_) / 64;                                           \
-    if ((S_) == 8) {                                                     \
-      if (v__ == 4) VSN_DISPATCH3(4, 8, W_, FN, __VA_ARGS__);            \
-      else if (v__ == 2) VSN_DISPATCH3(2, 8, W_, FN, __VA_ARGS__);       \
-      else if (v__ == 1) VSN_DISPATCH3(1, 8, W_, FN, __VA_ARGS__);       \
-      else return -22;                                                   \
-    } else if ((S_) == 3) {                                              \
-      if (v__ == 4) VSN_DISPATCH3(4, 3, W_, FN, __VA_ARGS__);            \
-      else if (v__ == 2) VSN_DISPATCH3(2, 3, W_, FN, __VA_ARGS__);       \
-      else if (v__ == 1) VSN_DISPATCH3(1, 3, W_, FN, __VA_ARGS__);       \
-      else return -22;                                                   \
-    } else return -22;                                                   \
+    switch ((H_) / 64) { /* hidden = 64 V, V = 1..8 */                   \
+      case 1: VSN_DISPATCH_V(1, S_, W_, FN, __VA_ARGS__); break;         \
+      case 2: VSN_DISPATCH_V(2, S_, W_, FN, __VA_ARGS__); break;         \
+      case 3: VSN_DISPATCH_V(3, S_, W_, FN, __VA_ARGS__); break;         \
+      case 4: VSN_DISPATCH_V(4, S_, W_, FN, __VA_ARGS__); break;         \
+      case 5: VSN_DISPATCH_V(5, S_, W_, FN, __VA_ARGS__); break;         \
+      case 6: VSN_DISPATCH_V(6, S_, W_, FN, __VA_ARGS__); break;         \
+      case 7: VSN_DISPATCH_V(7, S_, W_, FN, __VA_ARGS__); break;         \
+      case 8: VSN_DISPATCH_V(8, S_, W_, FN, __VA_ARGS__); break;         \
+      default: return -22;                                               \
+    }                                                                    \
   } while (0)
 
 // small batches (one protein per MD step): several waves per node
@@ -53,7 +58,8 @@ static inline int node_grid(int N, int wpn) {
 static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
 // LDS for node_reduce of K*V*64 floats per extra wave
 static inline size_t node_lds(int wpn, int K, int V) {
-  const int kc = K < 8 ? K : 8;  // VSN_REDUCE_ROWS
+  const int rmax = (32 / V) < 8 ? (32 / V) : 8;  // node_reduce: RMAX rows per pass
+  const int kc = K < rmax ? K : rmax;
   return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
 }
 
@@ -153,13 +159,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         float sp, dsp;
-        silu_both(pf[c], sp, dsp);
+        act_both(D.act, pf[c], sp, dsp);
         const float wd = dot[c] + a1[c] * a2[c] * cc;
         gpf[c] = gf[c] * wd * dsp;
         gwd[c] = gf[c] * sp;
       }
       strow<V>(g_pe + (size_t)e * 3 * H + 2 * H, lane, gpf);
-      float mine = 0.f;
+      constexpr int P = S <= 4 ? 4 : 8;
+      float pp[P];
+#pragma unroll
+      for (int s = 0; s < P; ++s) pp[s] = 0.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float p = 0.f;
@@ -168,9 +177,10 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
           gwt[s][c] += gwd[c] * (u2[s][c] + a2[c] * cc * dd[s]);
           p += gwd[c] * (cc * (a2[c] * wt[s][c] + a1[c] * u2[s][c]) + 2.0f * a1[c] * a2[c] * dd[s]);
         }
-        p = wave_sum(p);
-        if (lane == s) mine = p;
+        pp[s] = p;
       }
+      // the S per-component sums over the wave in ONE multi-value butterfly (was: S separate 6-step reductions)
+      const float mine = wave_multi_sum<P>(pp, lane);
       if (lane < S) g_geo[(size_t)e * 24 + 16 + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
     }
     node_reduce<V, S, WPN>(gwt, smem, lane, sub);
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
       ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
       ldrow<V>(g_f + (size_t)e * H, lane, gf);
 #pragma unroll
-      for (int c = 0; c < V; ++c) gwd[c] = gf[c] * silu_f(pf[c]);
+      for (int c = 0; c < V; ++c) gwd[c] = gf[c] * act_f(D.act, pf[c]);
 #pragma unroll
       for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -254,13 +264,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        d1[c] = dsilu_f(t1[c]);
-        silu_both(t2[c], s2[c], d2[c]);
+        d1[c] = dact_f(D.act, t1[c]);
+        act_both(D.act, t2[c], s2[c], d2[c]);
       }
       float gs1[V], gs2[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) gs1[c] = gs2[c] = 0.f;
-      float mine = 0.f;
+      constexpr int P = S <= 4 ? 4 : 8;
+      float pp[P];
+#pragma unroll
+      for (int s = 0; s < P; ++s) pp[s] = 0.f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float vj[V];
@@ -273,9 +286,9 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
           gs2[c] += gv[s][c] * ds;
           p += gv[s][c] * s2[c];
         }
-        p = wave_sum(p);
-        if (lane == s) mine = p;
+        pp[s] = p;
       }
+      const float mine = wave_multi_sum<P>(pp, lane);  // lane s < S: sum over the wave of component s
       if (lane < S) g_geo[(size_t)e * 24 + lane] = geo_old + mine;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
       float s1[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
 #pragma unroll
-      for (int c = 0; c < V; ++c) s1[c] = silu_f(s1[c]);
+      for (int c = 0; c < V; ++c) s1[c] = act_f(D.act, s1[c]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float gv[V];
@@ -334,7 +347,7 @@ template <int V, int S, int WPN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
-    float* __restrict__ g_geo) {
+    float* __restrict__ g_geo, Parts mp, Parts ap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   const int nh = D.nh;
@@ -344,7 +357,17 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], gA[V], gq[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
-    ldrow<V>(g_A + (size_t)i * H, lane, gA);
+    if (ap.n > 0) {  // dE/dA left as K-slices by the GEMM: sum them here, fixed order
+      ldrow<V>(ap.p + (size_t)i * H, lane, gA);
+      for (int k = 1; k < ap.n; ++k) {
+        float t[V];
+        ldrow<V>(ap.p + (size_t)k * ap.stride + (size_t)i * H, lane, t);
+#pragma unroll
+        for (int c = 0; c < V; ++c) gA[c] += t[c];
+      }
+    } else {
+      ldrow<V>(g_A + (size_t)i * H, lane, gA);
+    }
 #pragma unroll
     for (int c = 0; c < V; ++c) gq[0][c] = 0.f;
     for (int e = e0 + sub; e < e1; e += WPN) {
@@ -356,14 +379,24 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
-      ldrow<V>(g_m + (size_t)e * H, lane, gm);
+      if (mp.n > 0) {
+        ldrow<V>(mp.p + (size_t)e * H, lane, gm);
+        for (int k = 1; k < mp.n; ++k) {
+          float t[V];
+          ldrow<V>(mp.p + (size_t)k * mp.stride + (size_t)e * H, lane, t);
+#pragma unroll
+          for (int c = 0; c < V; ++c) gm[c] += t[c];
+        }
+      } else {
+        ldrow<V>(g_m + (size_t)e * H, lane, gm);
+      }
       float dk[V], ddk[V], dv[V], ddv[V];
       float part = 0.f, gpart = 0.f;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gm[c] += gA[c];
-        silu_both(pk[c], dk[c], ddk[c]);
-        silu_both(pv[c], dv[c], ddv[c]);
+        act_both(D.act, pk[c], dk[c], ddk[c]);
+        act_both(D.act, pv[c], dv[c], ddv[c]);
         part += q[c] * k[c] * dk[c];
         gpart += gm[c] * v[c] * dv[c];
       }
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       const float sat = group_sum(part, lph);
       const float ga = group_sum(gpart, lph);
       float ssat, dssat;
-      silu_both(sat, ssat, dssat);
+      act_both(D.attn_act, sat, ssat, dssat);
       const float a = ssat * C;
       const float gsat = ga * dssat * C;
       const bool head_lead = (lane & (lph - 1)) == 0;
@@ -424,8 +457,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
       const float a = sat_tmp[(size_t)e * 2 * nh + nh + lane / lph];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        g2[0][c] += gsat * q[c] * silu_f(pk[c]);
-        g2[1][c] += gm[c] * silu_f(pv[c]) * a;
+        g2[0][c] += gsat * q[c] * act_f(D.act, pk[c]);
+        g2[1][c] += gm[c] * act_f(D.act, pv[c]) * a;
       }
     }
     node_reduce<V, 2, WPN>(g2, smem, lane, sub);
@@ -799,9 +832,9 @@ int launch_bwd_vecmsg_S(hipStream_t st, const Dims& D, const float* g_vec, const
   return 0;
 }
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
-                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo) {
+                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo);
+  VSN_LAUNCH(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts);
   VSN_LAUNCH(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
   return 0;
 }

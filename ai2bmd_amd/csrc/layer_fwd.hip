@@ -24,20 +24,25 @@ namespace vsn {
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
     else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
   } while (0)
+#define VSN_DISPATCH_V(V_, S_, W_, FN, ...)                              \
+  do {                                                                   \
+    if ((S_) == 8) VSN_DISPATCH3(V_, 8, W_, FN, __VA_ARGS__);            \
+    else if ((S_) == 3) VSN_DISPATCH3(V_, 3, W_, FN, __VA_ARGS__);       \
+    else return -22;                                                     \
+  } while (0)
 #define VSN_DISPATCH_VS(H_, S_, W_, FN, ...)                             \
   do {                                                                   \
-    const int v__ = (H_) / 64;                                           \
-    if ((S_) == 8) {                                                     \
-      if (v__ == 4) VSN_DISPATCH3(4, 8, W_, FN, __VA_ARGS__);            \
-      else if (v__ == 2) VSN_DISPATCH3(2, 8, W_, FN, __VA_ARGS__);       \
-      else if (v__ == 1) VSN_DISPATCH3(1, 8, W_, FN, __VA_ARGS__);       \
-      else return -22;                                                   \
-    } else if ((S_) == 3) {                                              \
-      if (v__ == 4) VSN_DISPATCH3(4, 3, W_, FN, __VA_ARGS__);            \
-      else if (v__ == 2) VSN_DISPATCH3(2, 3, W_, FN, __VA_ARGS__);       \
-      else if (v__ == 1) VSN_DISPATCH3(1, 3, W_, FN, __VA_ARGS__);       \
-      else return -22;                                                   \
-    } else return -22;                                                   \
+    switch ((H_) / 64) { /* hidden = 64 V, V = 1..8 */                   \
+      case 1: VSN_DISPATCH_V(1, S_, W_, FN, __VA_ARGS__); break;         \
+      case 2: VSN_DISPATCH_V(2, S_, W_, FN, __VA_ARGS__); break;         \
+      case 3: VSN_DISPATCH_V(3, S_, W_, FN, __VA_ARGS__); break;         \
+      case 4: VSN_DISPATCH_V(4, S_, W_, FN, __VA_ARGS__); break;         \
+      case 5: VSN_DISPATCH_V(5, S_, W_, FN, __VA_ARGS__); break;         \
+      case 6: VSN_DISPATCH_V(6, S_, W_, FN, __VA_ARGS__); break;         \
+      case 7: VSN_DISPATCH_V(7, S_, W_, FN, __VA_ARGS__); break;         \
+      case 8: VSN_DISPATCH_V(8, S_, W_, FN, __VA_ARGS__); break;         \
+      default: return -22;                                               \
+    }                                                                    \
   } while (0)
 
 // small batches (one protein per MD step): several waves per node
@@ -51,7 +56,8 @@ static inline int node_grid(int N, int wpn) {
 static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
 // LDS for node_reduce of K*V*64 floats per extra wave
 static inline size_t node_lds(int wpn, int K, int V) {
-  const int kc = K < 8 ? K : 8;  // VSN_REDUCE_ROWS
+  const int rmax = (32 / V) < 8 ? (32 / V) : 8;  // node_reduce: RMAX rows per pass
+  const int kc = K < rmax ? K : rmax;
   return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
 }
 
@@ -195,12 +201,12 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
       float part = 0.f;
 #pragma unroll
-      for (int c = 0; c < V; ++c) part += q[c] * k[c] * silu_f(pk[c]);
+      for (int c = 0; c < V; ++c) part += q[c] * k[c] * act_f(D.act, pk[c]);
       const float sat = group_sum(part, lph);
-      const float a = silu_f(sat) * C;
+      const float a = act_f(D.attn_act, sat) * C;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        mv[c] = v[c] * silu_f(pv[c]) * a;
+        mv[c] = v[c] * act_f(D.act, pv[c]) * a;
         acc[0][c] += mv[c];
       }
       strow<V>(m + (size_t)e * H, lane, mv);
@@ -273,8 +279,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, s2);
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        s1[c] = silu_f(s1[c]);
-        s2[c] = silu_f(s2[c]);
+        s1[c] = act_f(D.act, s1[c]);
+        s2[c] = act_f(D.act, s2[c]);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
         for (int c = 0; c < V; ++c) Va[s][c] += vj[c] * s1[c] + ds * s2[c];
       }
     }
-    if constexpr (WPN > 1 && S <= WPN) {
+    if constexpr (WPN > 1 && S <= WPN && V <= 4) {
       // Small batches: instead of summing everything into wave 0 and letting it walk the S components alone,
       // reduce-SCATTER the partial sums (wave s receives the node total of component s) and let the S waves
       // update their component in parallel; only the channel-wise sum over s and the LayerNorm stay on wave 0.
@@ -417,7 +423,7 @@ __device__ __forceinline__ void edge_update_body(const Dims& D, const float* __r
       ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
       ldrow<V>(f + (size_t)e * H, lane, fv);
 #pragma unroll
-      for (int c = 0; c < V; ++c) fv[c] += silu_f(pf[c]) * (dot[c] + a1[c] * a2[c] * cc);
+      for (int c = 0; c < V; ++c) fv[c] += act_f(D.act, pf[c]) * (dot[c] + a1[c] * a2[c] * cc);
       strow<V>(f + (size_t)e * H, lane, fv);
     }
   }

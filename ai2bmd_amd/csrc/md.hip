@@ -9,8 +9,17 @@
 //           v += c1 F/m - c2 v + rnd_vel ; x += dt v + rnd_pos
 //   (forces at the new x)
 //   half2:  v += c1 F/m - c2 v + rnd_vel
-// with F = model force - k (x - x0) when a harmonic tether is configured (the reference's restrained
-// pre-equilibration uses Hookean restraints, simulator.py:139-166).
+// Restraints (the reference attaches ASE `Hookean` constraints: position restraints of all QM atoms during the
+// pre-equilibration stages, simulator.py:139-166, and X-H bond restraints with --hydrogen-constraints, :168-180):
+// a per-atom list of springs (towards a fixed point, or towards another atom) applied when the distance exceeds
+// its threshold rt:  F += k (r - rt) * unit(towards),  E += k (r - rt)^2 / 2 per spring.  half2 evaluates them at the
+// new positions, ADDS them into the force array it was handed (so the array the caller sees and the next half1
+// reads is model + restraints, like atoms.get_forces() in ASE) and leaves the per-atom restraint energy for
+// vsn_md_observe.  Per-atom lists, fixed order: no atomics, bit-reproducible.  A `tether_k` at creation is the
+// same thing for every atom towards its start position with rt = 0.
+// PARITY UNPINNED: ASE is not installed here, so the Langevin coefficients and the Hookean force law restate
+// ASE 3.22 from its published algorithm; tests check them against an independent torch restatement and analytic
+// properties only.
 #include <cmath>
 #include <vector>
 
@@ -64,7 +73,6 @@ __device__ __forceinline__ void normals6(unsigned long long seed, unsigned step,
 __global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restrict__ mass,
                                                    const float* __restrict__ c3, const float* __restrict__ c4,
                                                    const float* __restrict__ c5, float c1, float c2, float dt,
-                                                   float tether_k, const float* __restrict__ x0,
                                                    unsigned long long seed, unsigned step, float* __restrict__ x,
                                                    float* __restrict__ v, const float* __restrict__ F,
                                                    float* __restrict__ rnd_vel) {
@@ -106,8 +114,7 @@ __global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restric
       const float rp = c5[i] * eta - tot[k] * invn;
       const float rv = (c3[i] * xi - c4[i] * eta) - tot[3 + k] * invn / m;
       const size_t a = 3 * (size_t)i + k;
-      float f = F[a];
-      if (tether_k != 0.f) f -= tether_k * (x[a] - x0[a]);
+      const float f = F[a];  // model + restraint forces at the current positions (half2 / vsn_md_restrain added them)
       const float vn = v[a] + (c1 * f / m - c2 * v[a] + rv);
       v[a] = vn;
       x[a] = x[a] + dt * vn + rp;
@@ -116,15 +123,91 @@ __global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restric
   }
 }
 
-__global__ void k_md_half2(int n, const float* __restrict__ mass, float c1, float c2, float tether_k,
-                           const float* __restrict__ x0, const float* __restrict__ x, float* __restrict__ v,
-                           const float* __restrict__ F, const float* __restrict__ rnd_vel) {
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= 3 * n) return;
-  const float m = mass[a / 3];
-  float f = F[a];
-  if (tether_k != 0.f) f -= tether_k * (x[a] - x0[a]);
-  v[a] = v[a] + (c1 * f / m - c2 * v[a] + rnd_vel[a]);
+// One spring of an atom's list: towards a fixed point (partner < 0) or towards atom `partner`.
+struct Spring {
+  int partner;
+  float ox, oy, oz, k, rt;
+};
+
+// restraint force on atom i at positions x, and its share of the restraint energy (a pair spring is listed at both
+// ends and gives half its energy to each)
+__device__ __forceinline__ void restraint_of(int i, const float* __restrict__ x, const int* __restrict__ ptr,
+                                             const Spring* __restrict__ sp, float (&f)[3], float& e) {
+  f[0] = f[1] = f[2] = 0.f;
+  e = 0.f;
+  const float xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
+  for (int t = ptr[i]; t < ptr[i + 1]; ++t) {
+    const Spring s = sp[t];
+    float dx, dy, dz;
+    if (s.partner >= 0) {
+      dx = x[3 * (size_t)s.partner] - xi, dy = x[3 * (size_t)s.partner + 1] - yi, dz = x[3 * (size_t)s.partner + 2] - zi;
+    } else {
+      dx = s.ox - xi, dy = s.oy - yi, dz = s.oz - zi;
+    }
+    const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (r > s.rt && r > 0.f) {
+      const float mag = s.k * (r - s.rt) / r;
+      f[0] += mag * dx, f[1] += mag * dy, f[2] += mag * dz;
+      e += (s.partner >= 0 ? 0.25f : 0.5f) * s.k * (r - s.rt) * (r - s.rt);
+    }
+  }
+}
+
+// F += restraints(x); e_r[i] = restraint energy share of atom i   (used once, for the forces of the start geometry)
+__global__ void k_md_restrain(int n, const float* __restrict__ x, float* __restrict__ F, const int* __restrict__ ptr,
+                              const Spring* __restrict__ sp, float* __restrict__ e_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float f[3], e;
+  restraint_of(i, x, ptr, sp, f, e);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) F[3 * (size_t)i + k] += f[k];
+  e_r[i] = e;
+}
+
+// second half of the step, one thread per atom: restraints at the new positions are added INTO F, then
+// v += c1 F/m - c2 v + rnd_vel
+__global__ void k_md_half2(int n, const float* __restrict__ mass, float c1, float c2, const float* __restrict__ x,
+                           float* __restrict__ v, float* __restrict__ F, const float* __restrict__ rnd_vel,
+                           const int* __restrict__ ptr, const Spring* __restrict__ sp, float* __restrict__ e_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float fr[3] = {0.f, 0.f, 0.f}, e = 0.f;
+  if (ptr) restraint_of(i, x, ptr, sp, fr, e);
+  const float m = mass[i];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const size_t a = 3 * (size_t)i + k;
+    const float f = F[a] + fr[k];
+    if (ptr) F[a] = f;
+    v[a] = v[a] + (c1 * f / m - c2 * v[a] + rnd_vel[a]);
+  }
+  if (ptr) e_r[i] = e;
+}
+
+// observables without leaving HBM: out[0] = kinetic energy sum m v^2 / 2, out[1] = restraint energy,
+// out[2] = temperature 2 Ekin / (3 n kB)  (ASE Atoms.get_temperature with 3 n degrees of freedom)
+__global__ __launch_bounds__(1024) void k_md_observe(int n, const float* __restrict__ mass, const float* __restrict__ v,
+                                                     const float* __restrict__ e_r, float kB, float* __restrict__ out) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ek = 0.f, er = 0.f;
+  for (int i = tid; i < n; i += blockDim.x) {
+    const float vx = v[3 * (size_t)i], vy = v[3 * (size_t)i + 1], vz = v[3 * (size_t)i + 2];
+    ek += 0.5f * mass[i] * (vx * vx + vy * vy + vz * vz);
+    if (e_r) er += e_r[i];
+  }
+  ek = wave_sum(ek);
+  er = wave_sum(er);
+  if (lane == 0) red[0][wave] = ek, red[1][wave] = er;
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += red[0][w], b += red[1][w];
+    out[0] = a;
+    out[1] = b;
+    out[2] = 2.0f * a / (3.0f * (float)n * kB);
+  }
 }
 
 }  // namespace vsn
@@ -134,8 +217,36 @@ struct vsn_md {
   float c1 = 0, c2 = 0, dt = 0, tether_k = 0;
   unsigned long long seed = 0;
   unsigned step = 0;
-  float *mass = nullptr, *c3 = nullptr, *c4 = nullptr, *c5 = nullptr, *x0 = nullptr, *rnd_vel = nullptr;
+  float *mass = nullptr, *c3 = nullptr, *c4 = nullptr, *c5 = nullptr, *rnd_vel = nullptr;
+  int* sp_ptr = nullptr;          // [n+1] CSR over atoms of the restraint springs, nullptr = none
+  vsn::Spring* sp = nullptr;
+  float* e_r = nullptr;           // [n] per-atom restraint energy of the last evaluation
+  float* obs = nullptr;           // [4] observables
 };
+
+static int set_springs(vsn_md* p, const std::vector<std::vector<vsn::Spring>>& per_atom) {
+  hipFree(p->sp_ptr);
+  hipFree(p->sp);
+  p->sp_ptr = nullptr;
+  p->sp = nullptr;
+  size_t tot = 0;
+  for (auto& v : per_atom) tot += v.size();
+  hipMemset(p->e_r, 0, (size_t)p->n * sizeof(float));
+  if (tot == 0) return 0;
+  std::vector<int> ptr((size_t)p->n + 1, 0);
+  std::vector<vsn::Spring> flat;
+  flat.reserve(tot);
+  for (int i = 0; i < p->n; ++i) {
+    ptr[(size_t)i + 1] = ptr[(size_t)i] + (int)per_atom[(size_t)i].size();
+    flat.insert(flat.end(), per_atom[(size_t)i].begin(), per_atom[(size_t)i].end());
+  }
+  if (hipMalloc((void**)&p->sp_ptr, ptr.size() * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&p->sp, flat.size() * sizeof(vsn::Spring)) != hipSuccess)
+    return -12;
+  hipMemcpy(p->sp_ptr, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice);
+  hipMemcpy(p->sp, flat.data(), flat.size() * sizeof(vsn::Spring), hipMemcpyHostToDevice);
+  return 0;
+}
 
 extern "C" int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n, const float* host_mass, float dt,
                              float kT, float friction, uint64_t seed, float tether_k, const float* host_x0) {
@@ -161,7 +272,8 @@ extern "C" int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n, const
   const size_t nb = (size_t)n * sizeof(float);
   bool ok = hipMalloc((void**)&p->mass, nb) == hipSuccess && hipMalloc((void**)&p->c3, nb) == hipSuccess &&
             hipMalloc((void**)&p->c4, nb) == hipSuccess && hipMalloc((void**)&p->c5, nb) == hipSuccess &&
-            hipMalloc((void**)&p->x0, 3 * nb) == hipSuccess && hipMalloc((void**)&p->rnd_vel, 3 * nb) == hipSuccess;
+            hipMalloc((void**)&p->rnd_vel, 3 * nb) == hipSuccess && hipMalloc((void**)&p->e_r, nb) == hipSuccess &&
+            hipMalloc((void**)&p->obs, 4 * sizeof(float)) == hipSuccess;
   if (!ok) {
     delete p;
     return -12;
@@ -170,8 +282,19 @@ extern "C" int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n, const
   hipMemcpy(p->c3, c3.data(), nb, hipMemcpyHostToDevice);
   hipMemcpy(p->c4, c4.data(), nb, hipMemcpyHostToDevice);
   hipMemcpy(p->c5, c5.data(), nb, hipMemcpyHostToDevice);
-  if (host_x0) hipMemcpy(p->x0, host_x0, 3 * nb, hipMemcpyHostToDevice);
   hipMemset(p->rnd_vel, 0, 3 * nb);
+  hipMemset(p->e_r, 0, nb);
+  hipMemset(p->obs, 0, 4 * sizeof(float));
+  if (tether_k != 0.f) {  // every atom on a spring to its start position, rt = 0
+    std::vector<std::vector<vsn::Spring>> per((size_t)n);
+    for (int64_t i = 0; i < n; ++i)
+      per[(size_t)i].push_back(vsn::Spring{-1, host_x0[3 * i], host_x0[3 * i + 1], host_x0[3 * i + 2], tether_k, 0.f});
+    int rc = set_springs(p, per);
+    if (rc) {
+      vsn_md_destroy(p);
+      return rc;
+    }
+  }
   *out = p;
   return 0;
 }
@@ -183,8 +306,11 @@ extern "C" void vsn_md_destroy(vsn_md_handle p) {
   hipFree(p->c3);
   hipFree(p->c4);
   hipFree(p->c5);
-  hipFree(p->x0);
   hipFree(p->rnd_vel);
+  hipFree(p->sp_ptr);
+  hipFree(p->sp);
+  hipFree(p->e_r);
+  hipFree(p->obs);
   delete p;
 }
 
@@ -192,16 +318,52 @@ extern "C" int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const f
   if (!p) return -22;
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   hipLaunchKernelGGL(vsn::k_md_half1, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->n, p->mass, p->c3, p->c4, p->c5,
-                     p->c1, p->c2, p->dt, p->tether_k, p->x0, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel);
+                     p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel);
   p->step++;
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 
-extern "C" int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, const float* dev_F, void* stream) {
+extern "C" int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, float* dev_F, void* stream) {
   if (!p) return -22;
   if (hipSetDevice(p->device) != hipSuccess) return -19;
-  const int n3 = 3 * p->n;
-  hipLaunchKernelGGL(vsn::k_md_half2, dim3((n3 + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->n, p->mass,
-                     p->c1, p->c2, p->tether_k, p->x0, dev_x, dev_v, dev_F, p->rnd_vel);
+  hipLaunchKernelGGL(vsn::k_md_half2, dim3((p->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->n, p->mass,
+                     p->c1, p->c2, dev_x, dev_v, dev_F, p->rnd_vel, p->sp_ptr, p->sp, p->e_r);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_set_restraints(vsn_md_handle p, int64_t n_point, const int64_t* atom, const float* origin3,
+                                     const float* k_point, const float* rt_point, int64_t n_pair, const int64_t* a1,
+                                     const int64_t* a2, const float* k_pair, const float* rt_pair) {
+  if (!p || n_point < 0 || n_pair < 0) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  std::vector<std::vector<vsn::Spring>> per((size_t)p->n);
+  for (int64_t t = 0; t < n_point; ++t) {
+    if (atom[t] < 0 || atom[t] >= p->n) return -22;
+    per[(size_t)atom[t]].push_back(
+        vsn::Spring{-1, origin3[3 * t], origin3[3 * t + 1], origin3[3 * t + 2], k_point[t], rt_point[t]});
+  }
+  for (int64_t t = 0; t < n_pair; ++t) {
+    if (a1[t] < 0 || a1[t] >= p->n || a2[t] < 0 || a2[t] >= p->n || a1[t] == a2[t]) return -22;
+    per[(size_t)a1[t]].push_back(vsn::Spring{(int)a2[t], 0.f, 0.f, 0.f, k_pair[t], rt_pair[t]});
+    per[(size_t)a2[t]].push_back(vsn::Spring{(int)a1[t], 0.f, 0.f, 0.f, k_pair[t], rt_pair[t]});
+  }
+  hipDeviceSynchronize();  // the previous lists may still be read by a queued step
+  return set_springs(p, per);
+}
+
+extern "C" int vsn_md_restrain(vsn_md_handle p, const float* dev_x, float* dev_F, void* stream) {
+  if (!p) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  if (!p->sp_ptr) return 0;
+  hipLaunchKernelGGL(vsn::k_md_restrain, dim3((p->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->n, dev_x,
+                     dev_F, p->sp_ptr, p->sp, p->e_r);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_observe(vsn_md_handle p, const float* dev_v, float kB, float* dev_out3, void* stream) {
+  if (!p || !dev_v || !dev_out3) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  hipLaunchKernelGGL(vsn::k_md_observe, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->n, p->mass, dev_v,
+                     p->sp_ptr ? p->e_r : nullptr, kB, dev_out3);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -216,20 +216,25 @@ __global__ __launch_bounds__(256) void k_vecnorm_bwd(int N, int H, int norm_type
   }
 }
 
-#define VSN_DISPATCH2(H_, S_, FN, ...)                \
+#define VSN_DISPATCH2V(V_, S_, FN, ...)               \
   do {                                                \
-    const int v__ = (H_) / 64;                        \
-    if ((S_) == 8) {                                  \
-      if (v__ == 4) FN<4, 8> __VA_ARGS__;             \
-      else if (v__ == 2) FN<2, 8> __VA_ARGS__;        \
-      else if (v__ == 1) FN<1, 8> __VA_ARGS__;        \
-      else return -22;                                \
-    } else if ((S_) == 3) {                           \
-      if (v__ == 4) FN<4, 3> __VA_ARGS__;             \
-      else if (v__ == 2) FN<2, 3> __VA_ARGS__;        \
-      else if (v__ == 1) FN<1, 3> __VA_ARGS__;        \
-      else return -22;                                \
-    } else return -22;                                \
+    if ((S_) == 8) FN<V_, 8> __VA_ARGS__;             \
+    else if ((S_) == 3) FN<V_, 3> __VA_ARGS__;        \
+    else return -22;                                  \
+  } while (0)
+#define VSN_DISPATCH2(H_, S_, FN, ...)                              \
+  do {                                                              \
+    switch ((H_) / 64) {                                            \
+      case 1: VSN_DISPATCH2V(1, S_, FN, __VA_ARGS__); break;        \
+      case 2: VSN_DISPATCH2V(2, S_, FN, __VA_ARGS__); break;        \
+      case 3: VSN_DISPATCH2V(3, S_, FN, __VA_ARGS__); break;        \
+      case 4: VSN_DISPATCH2V(4, S_, FN, __VA_ARGS__); break;        \
+      case 5: VSN_DISPATCH2V(5, S_, FN, __VA_ARGS__); break;        \
+      case 6: VSN_DISPATCH2V(6, S_, FN, __VA_ARGS__); break;        \
+      case 7: VSN_DISPATCH2V(7, S_, FN, __VA_ARGS__); break;        \
+      case 8: VSN_DISPATCH2V(8, S_, FN, __VA_ARGS__); break;        \
+      default: return -22;                                          \
+    }                                                               \
   } while (0)
 
 int launch_vecnorm_fwd(hipStream_t st, int N, int H, int S, int norm_type, const float* vec, const float* w,

@@ -45,7 +45,15 @@ class MMNonBondedCalculator:
         self._h = None
         self.n = 0
 
-    def set_parameters(self, prot, plan: FragmentPlan) -> None:
+    def set_parameters(self, prot, plan: FragmentPlan = None) -> None:
+        """`prot.charges / sigmas / epsilons` like the reference (nonbonded.py:24-31).  The pair exclusions come from
+        the fragment plan DistanceFragment.fragment(prot) left on `prot` (the reference reads prot.exclude_pair through
+        prot.initial_mm_adjmatrix(), protein.py:133-151); `plan` overrides it."""
+        if plan is None:
+            plan = getattr(prot, "_vsn_plan", None)
+            if plan is None:
+                raise RuntimeError("MMNonBondedCalculator.set_parameters: call DistanceFragment.fragment(prot) first "
+                                   "(simulator.py:53-57 does), or pass the FragmentPlan")
         q = np.ascontiguousarray(prot.charges, dtype=np.float32)
         s = np.ascontiguousarray(prot.sigmas, dtype=np.float32)
         e = np.ascontiguousarray(prot.epsilons, dtype=np.float32)
@@ -72,7 +80,8 @@ class MMNonBondedCalculator:
         return self._e, f
 
     def __call__(self, prot):
-        pos = torch.as_tensor(np.ascontiguousarray(prot.positions, dtype=np.float32)).to(self.device)
+        xyz = prot.get_positions() if hasattr(prot, "get_positions") else prot.positions
+        pos = torch.as_tensor(np.ascontiguousarray(xyz, dtype=np.float32)).to(self.device)
         e, f = self.forces_device(pos)
         return float(e.cpu()[0]), f.cpu().numpy()
 

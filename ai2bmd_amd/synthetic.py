@@ -74,6 +74,10 @@ def rbf_params(hp):
         beta = np.float32((2.0 / R * (1.0 - float(start))) ** -2)
         betas = np.full(R, beta, np.float32)
         return means, betas
+    if hp["rbf_type"] == "gauss":
+        offset = np.linspace(np.float32(0.0), rc, R, dtype=np.float32)
+        coeff = np.float32(-0.5 / float(offset[1] - offset[0]) ** 2)
+        return offset, coeff
     raise NotImplementedError(hp["rbf_type"])
 
 
@@ -91,9 +95,14 @@ def make_state_dict(hp, seed=0, trivial=False):
     sd["std"] = np.float32(1.0 if trivial else 1.9)
     rm = "representation_model."
     sd[rm + "embedding.weight"] = rng.standard_normal((Z, H)).astype(np.float32)
-    means, betas = rbf_params(hp)
-    sd[rm + "distance_expansion.means"] = means
-    sd[rm + "distance_expansion.betas"] = betas
+    if hp["rbf_type"] == "gauss":  # GaussianSmearing registers `coeff` (0-d) then `offset` (utils.py:66-73)
+        offset, coeff = rbf_params(hp)
+        sd[rm + "distance_expansion.coeff"] = coeff
+        sd[rm + "distance_expansion.offset"] = offset
+    else:
+        means, betas = rbf_params(hp)
+        sd[rm + "distance_expansion.means"] = means
+        sd[rm + "distance_expansion.betas"] = betas
     sd[rm + "neighbor_embedding.embedding.weight"] = rng.standard_normal((Z, H)).astype(np.float32)
     sd[rm + "neighbor_embedding.distance_proj.weight"] = _xavier(rng, H, R)
     sd[rm + "neighbor_embedding.distance_proj.bias"] = _bias(rng, H, trivial)

@@ -41,8 +41,8 @@ class ViSNetEngine:
         self.hparams = dict(hparams)
         L = capi.lib()
         self._L = L
-        for key, ok in (("rbf_type", ("expnorm",)), ("activation", ("silu", "swish")),
-                        ("attn_activation", ("silu", "swish")), ("model", ("ViSNetBlock",)),
+        for key, ok in (("rbf_type", tuple(capi.RBF)), ("activation", tuple(capi.ACTIVATION)),
+                        ("attn_activation", tuple(capi.ACTIVATION)), ("model", ("ViSNetBlock",)),
                         ("output_model", ("Scalar",)), ("reduce_op", ("add",))):
             if hparams.get(key, ok[0]) not in ok:
                 raise NotImplementedError(f"{key}={hparams.get(key)!r} is not built in the HIP path (supported: {ok})")
@@ -60,6 +60,9 @@ class ViSNetEngine:
             vecnorm_type=capi.VECNORM[hparams["vecnorm_type"]],
             has_atomref=1 if prior == "Atomref" else 0,
             cutoff=float(hparams["cutoff"]),
+            rbf_type=capi.RBF[hparams.get("rbf_type", "expnorm")],
+            activation=capi.ACTIVATION[hparams.get("activation", "silu")],
+            attn_activation=capi.ACTIVATION[hparams.get("attn_activation", "silu")],
         )
         self._h = C.c_void_p()
         rc = L.vsn_create(C.byref(self._h), C.byref(hp), self.index)
@@ -157,14 +160,54 @@ class ViSNetEngine:
             pass
 
 
-def load_checkpoint(filepath):
-    """Reads a Lightning-style checkpoint the way load_model does
-    (ViSNet/model/visnet.py:73-87): hyper-parameters from the file itself,
-    'model.' prefix stripped from the state_dict keys."""
+class LoadedViSNet:
+    """What `load_model` returns here: the checkpoint's hyper-parameters and tensors (the reference returns a
+    scripted torch module; this package evaluates the network with its own kernels, so the 'model' is its weights)."""
+
+    def __init__(self, hparams: dict, state_dict: dict):
+        self.hparams, self.state = dict(hparams), dict(state_dict)
+
+    def state_dict(self):
+        return self.state
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+
+def load_model(filepath, device="cpu"):
+    """Mirror of ViSNet/model/visnet.py:73-93: reads the Lightning-style checkpoint - hyper-parameters from the
+    file itself, 'model.' prefix stripped from the state_dict keys - and returns the loaded model object that
+    `ViSNetModel(model, device)` takes."""
     ckpt = torch.load(filepath, map_location="cpu", weights_only=False)
     hp = ckpt["hyper_parameters"]
     sd = {re.sub(r"^model\.", "", k): v for k, v in ckpt["state_dict"].items()}
-    return hp, sd
+    return LoadedViSNet(hp, sd)
+
+
+def load_checkpoint(filepath):
+    m = load_model(filepath)
+    return m.hparams, m.state
+
+
+def hparams_of_module(model) -> dict:
+    """Hyper-parameters of a torch ViSNet module built by the reference's create_model (visnet.py:14-70), read off
+    the attributes ViSNetBlock keeps (visnet_block.py:40-55) - so that a reference module can be handed to
+    `ViSNetModel(model, device)` exactly where the reference constructs its own."""
+    rep = model.representation_model
+    layer = rep.vis_mp_layers[0]
+    names = {"SiLU": "silu", "Swish": "swish", "ShiftedSoftplus": "ssp", "Tanh": "tanh", "Sigmoid": "sigmoid"}
+    prior = getattr(model, "prior_model", None)
+    return dict(
+        model="ViSNetBlock", output_model="Scalar", reduce_op=getattr(model, "reduce_op", "add"),
+        embedding_dimension=int(rep.hidden_channels), num_layers=int(rep.num_layers), num_rbf=int(rep.num_rbf),
+        num_heads=int(rep.num_heads), lmax=int(rep.lmax), max_z=int(rep.max_z), cutoff=float(rep.cutoff),
+        max_num_neighbors=int(rep.max_num_neighbors), vecnorm_type=rep.vecnorm_type, rbf_type=rep.rbf_type,
+        activation=names[type(layer.act).__name__], attn_activation=names[type(layer.attn_activation).__name__],
+        prior_model="Atomref" if prior is not None else None,
+    )
 
 
 class ViSNetModel:
@@ -173,9 +216,21 @@ class ViSNetModel:
 
     implemented_properties = ["energy", "forces"]
 
-    def __init__(self, hparams, state_dict, device="cuda:0"):
+    def __init__(self, model, state_dict=None, device="cuda:0"):
+        """`ViSNetModel(model, device=...)` like the reference (:35): `model` is what `load_model` returned, or a torch
+        ViSNet module built by the reference's create_model.  The three-argument form `(hparams, state_dict, device)`
+        builds one from in-memory weights."""
+        if state_dict is not None:
+            hparams, sd = model, state_dict
+        elif isinstance(model, LoadedViSNet):
+            hparams, sd = model.hparams, model.state
+        elif isinstance(model, torch.nn.Module):
+            hparams, sd = hparams_of_module(model), model.state_dict()
+        else:
+            raise TypeError(f"ViSNetModel: cannot take a model of type {type(model).__name__}")
+        self.model = model
         self.device = device
-        self.engine = ViSNetEngine(hparams, state_dict, device)
+        self.engine = ViSNetEngine(hparams, sd, device)
         self.stream = torch.cuda.Stream(device=device)
 
     def collate(self, frag: FragmentData):
@@ -206,21 +261,33 @@ class ViSNetModel:
     def from_file(cls, **kwargs):
         if "model_path" not in kwargs:
             raise ValueError("model_path must be provided")
-        hp, sd = load_checkpoint(kwargs["model_path"])
-        return cls(hp, sd, device=kwargs.get("device", "cuda:0"))
+        model = load_model(kwargs["model_path"])
+        return cls(model, device=kwargs.get("device", "cuda:0"))
 
 
 class ViSNetCalculator:
-    r"""Whole-molecule mode (`--mode visnet`): one fragment = the whole system
-    (mirror of Calculators/visnet_calculator.py:121-155; ASE's Calculator base is
-    not available here, so this class implements the same `calculate(atoms,
-    properties, system_changes)` / `.results` protocol stand-alone)."""
+    r"""Whole-molecule mode (`--mode visnet`): one fragment = the whole system (mirror of
+    Calculators/visnet_calculator.py:121-155, same constructor).  ASE's Calculator base class is not importable in
+    this package's test environment, so the class implements the `calculate(atoms, properties, system_changes)` /
+    `.results` / `implemented_properties` protocol stand-alone; with ASE present, list `ase.calculators.calculator.
+    Calculator` as a second base - nothing else changes."""
 
     implemented_properties = ["energy", "forces"]
 
-    def __init__(self, model: ViSNetModel):
-        self.model = model
+    def __init__(self, ckpt_path: str = None, ckpt_type: str = None, is_root_calc=True, model: ViSNetModel = None,
+                 **kwargs):
+        import os.path as osp
+
+        from .device_strategy import DeviceStrategy
+
+        self.ckpt_path, self.ckpt_type, self.is_root_calc = ckpt_path, ckpt_type, is_root_calc
         self.results = {}
+        if model is not None:  # embedding aid: an already constructed seam object
+            self.model, self.device = model, model.device
+            return
+        model_path = osp.join(self.ckpt_path, f"visnet-uni-{self.ckpt_type}.ckpt")
+        self.device = DeviceStrategy.get_bonded_devices()[0]
+        self.model = get_visnet_model(model_path, self.device)
 
     def calculate(self, atoms, properties=("energy", "forces"), system_changes=None):
         n = len(atoms)

@@ -41,12 +41,15 @@ extern "C" {
 typedef struct vsn_ctx* vsn_handle;
 
 enum { VSN_VECNORM_NONE = 0, VSN_VECNORM_RMS = 1, VSN_VECNORM_MAXMIN = 2 };
+enum { VSN_RBF_EXPNORM = 0, VSN_RBF_GAUSS = 1 };
+/* act_class_mapping (ViSNet/model/utils.py:93-116): "silu" and "swish" are the same function */
+enum { VSN_ACTIVATION_SILU = 0, VSN_ACTIVATION_SSP = 1, VSN_ACTIVATION_TANH = 2, VSN_ACTIVATION_SIGMOID = 3 };
 
 /* Hyper-parameters read by create_model (ViSNet/model/visnet.py:15-30). */
 typedef struct vsn_hparams {
-  int32_t hidden;            /* embedding_dimension (64 | 128 | 256)            */
+  int32_t hidden;            /* embedding_dimension: a multiple of 64, 64..512 */
   int32_t num_layers;        /* num_layers                                     */
-  int32_t num_rbf;           /* num_rbf, expnorm basis                         */
+  int32_t num_rbf;           /* num_rbf                                        */
   int32_t num_heads;         /* power of two dividing 64                       */
   int32_t lmax;              /* 1 | 2                                          */
   int32_t max_z;             /* embedding rows                                 */
@@ -54,6 +57,9 @@ typedef struct vsn_hparams {
   int32_t vecnorm_type;      /* VSN_VECNORM_*                                  */
   int32_t has_atomref;       /* prior_model == "Atomref" (table length = prior_args.max_z, taken from the tensor) */
   float cutoff;              /* Angstrom                                       */
+  int32_t rbf_type;          /* VSN_RBF_EXPNORM | VSN_RBF_GAUSS   (utils.py:22-90 rbf_class_mapping)      */
+  int32_t activation;        /* VSN_ACT_* of "activation": dk/dv/s_proj/f_proj and the read-out MLPs       */
+  int32_t attn_activation;   /* VSN_ACT_* of "attn_activation": the attention scores (visnet_block.py:278) */
 } vsn_hparams;
 
 int vsn_create(vsn_handle* out, const vsn_hparams* hp, int device_id);
@@ -146,15 +152,31 @@ void vsn_fragplan_destroy(vsn_fragplan_handle p);
 int vsn_build_fragments(vsn_fragplan_handle p, const float* dev_prot_pos, float* dev_frag_pos, void* stream);
 
 /* ---- Langevin integrator step on the device (AIMD/simulator.py:96-116 -> ASE Langevin.step) ----
- * ASE units (eV, Angstrom, amu): dt and friction in ASE time units, kT in eV.  tether_k > 0 adds
- * -k (x - x0) to the forces (x0 = host_x0).  One step = vsn_md_half1, force evaluation at the new
- * positions, vsn_md_half2. */
+ * ASE units (eV, Angstrom, amu): dt and friction in ASE time units, kT in eV.  One step = vsn_md_half1, force
+ * evaluation at the new positions into dev_F, vsn_md_half2.  Restraints (ASE `Hookean`, simulator.py:139-180) are
+ * evaluated by half2 at the new positions and ADDED INTO dev_F, so dev_F = model + restraint forces afterwards
+ * (what atoms.get_forces() returns in ASE) and the next half1 reads it as is; call vsn_md_restrain once for the
+ * forces of the start geometry.  tether_k > 0 = every atom restrained to host_x0 with threshold 0.
+ * PARITY UNPINNED (ASE absent): the coefficients and the Hookean law restate ASE 3.22's published algorithm. */
 typedef struct vsn_md* vsn_md_handle;
 int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n_atoms, const float* host_mass, float dt, float kT,
                   float friction, uint64_t seed, float tether_k, const float* host_x0);
 void vsn_md_destroy(vsn_md_handle p);
 int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, void* stream);
-int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, const float* dev_F, void* stream);
+int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, float* dev_F, void* stream);
+/* Replaces the restraint set (synchronises the device).  Point springs: atom[t] towards origin3[3t..], force
+ * k (r - rt) along the line when r > rt, energy k (r - rt)^2 / 2 - `Hookean(a1=idx, a2=pos, k, rt)`, the
+ * pre-equilibration stages (simulator.py:139-166).  Pair springs between atoms a1[t], a2[t] - `Hookean(a1, a2, k, rt)`,
+ * the X-H bond restraints of --hydrogen-constraints (simulator.py:168-180).  n_point = n_pair = 0 removes all. */
+int vsn_md_set_restraints(vsn_md_handle p, int64_t n_point, const int64_t* host_atom, const float* host_origin3,
+                          const float* host_k_point, const float* host_rt_point, int64_t n_pair,
+                          const int64_t* host_a1, const int64_t* host_a2, const float* host_k_pair,
+                          const float* host_rt_pair);
+/* dev_F += restraint forces at dev_x (start geometry; half2 does this itself on every step) */
+int vsn_md_restrain(vsn_md_handle p, const float* dev_x, float* dev_F, void* stream);
+/* observer hook (utils/utils.py:143-159 printenergy) without a host round trip: dev_out3 = {kinetic energy,
+ * restraint energy of the last evaluation, temperature = 2 Ekin / (3 n kB)} */
+int vsn_md_observe(vsn_md_handle p, const float* dev_v, float kB, float* dev_out3, void* stream);
 
 /* ---- MM non-bonded term between atoms that do not share a dipeptide (Calculators/nonbonded.py:33-63) ----
  * charges [e], sigma [nm], epsilon [kJ/mol] as OpenMM gives them (AIMD/protein.py:153-175);

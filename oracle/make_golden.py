@@ -33,6 +33,22 @@ CASES = {
     "h64_l3_rms": (dict(embedding_dimension=64, num_layers=3, vecnorm_type="rms"), 15, 105, [24, 12]),
     "h64_l3_maxmin": (dict(embedding_dimension=64, num_layers=3, vecnorm_type="max_min"), 16, 106, [24, 12]),
     "h64_l2_whole": (dict(embedding_dimension=64, num_layers=2), 17, 107, [120]),
+    # hyper-parameters a checkpoint may legally carry (visnet.py:74-76 reads them from the file): the other
+    # radial basis (utils.py:60-90), the other activations (utils.py:93-116), any hidden width that is a multiple of 64
+    "h64_l2_gauss": (dict(embedding_dimension=64, num_layers=2, rbf_type="gauss"), 18, 108, [22, 12, 30]),
+    "h128_l2_gauss_lmax1": (dict(embedding_dimension=128, num_layers=2, rbf_type="gauss", lmax=1, num_rbf=20), 19, 109,
+                            [26, 12]),
+    "h64_l2_ssp": (dict(embedding_dimension=64, num_layers=2, activation="ssp", attn_activation="ssp"), 20, 110,
+                   [22, 12, 19]),
+    "h64_l2_tanh_sig": (dict(embedding_dimension=64, num_layers=2, activation="tanh", attn_activation="sigmoid"), 21, 111,
+                        [24, 12]),
+    "h128_l2_sig_swish": (dict(embedding_dimension=128, num_layers=2, activation="sigmoid", attn_activation="swish"), 22,
+                          112, [28, 12]),
+    "h192_l2": (dict(embedding_dimension=192, num_layers=2), 23, 113, [22, 12, 27]),
+    "h320_l2_rms": (dict(embedding_dimension=320, num_layers=2, vecnorm_type="rms"), 24, 114, [24, 12]),
+    "h384_l2_lmax1": (dict(embedding_dimension=384, num_layers=2, lmax=1), 25, 115, [30, 12]),
+    "h448_l2": (dict(embedding_dimension=448, num_layers=2, num_heads=4), 26, 116, [19, 12]),
+    "h512_l3": (dict(embedding_dimension=512, num_layers=3), 27, 117, [22, 12, 33]),
 }
 
 
@@ -59,6 +75,8 @@ def main():
     out_dir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     for name, (over, wseed, iseed, sizes) in CASES.items():
+        if os.path.exists(os.path.join(out_dir, f"visnet_{name}.npz")) and "--all" not in sys.argv:
+            continue  # committed fixtures stay byte-identical; `--all` regenerates everything
         hp = default_hparams(**over)
         sd = make_state_dict(hp, seed=wseed)
         z, pos, start, end = random_fragments(iseed, sizes, cutoff=hp["cutoff"])

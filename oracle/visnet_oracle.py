@@ -48,6 +48,20 @@ def dsilu(x):
     return s * (1.0 + x * (1.0 - s))
 
 
+def _softplus_shift(x):
+    return torch.nn.functional.softplus(x) - math.log(2.0)
+
+
+# the reference's activation table (utils.py:93-116): name -> (f, f')
+ACTIVATIONS = {
+    "silu": (silu, dsilu),
+    "swish": (silu, dsilu),
+    "ssp": (_softplus_shift, torch.sigmoid),
+    "tanh": (torch.tanh, lambda x: 1.0 - torch.tanh(x) ** 2),
+    "sigmoid": (torch.sigmoid, lambda x: torch.sigmoid(x) * (1.0 - torch.sigmoid(x))),
+}
+
+
 def cosine_cutoff(r, rc):
     """utils.py:16-19"""
     return 0.5 * (torch.cos(r * (math.pi / rc)) + 1.0) * (r < rc).to(r.dtype)
@@ -179,8 +193,8 @@ class ViSNetOracle:
     def __init__(self, hp, sd, dtype=torch.float64):
         self.hp = dict(hp)
         self.dtype = dtype
-        if hp["rbf_type"] != "expnorm":
-            raise NotImplementedError("oracle restates the expnorm basis only")
+        if hp["rbf_type"] not in ("expnorm", "gauss"):
+            raise NotImplementedError(hp["rbf_type"])
         self.H = hp["embedding_dimension"]
         self.L = hp["num_layers"]
         self.R = hp["num_rbf"]
@@ -192,8 +206,8 @@ class ViSNetOracle:
         self.max_nb = hp["max_num_neighbors"]
         self.vn = hp["vecnorm_type"]
         self.alpha = 5.0 / self.rc
-        if hp["activation"] not in ("silu", "swish") or hp["attn_activation"] not in ("silu", "swish"):
-            raise NotImplementedError("oracle restates silu/swish activations only")
+        self.act, self.dact = ACTIVATIONS[hp["activation"]]
+        self.aact, self.daact = ACTIVATIONS[hp["attn_activation"]]
         self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in sd.items()}
         self.has_atomref = "prior_model.atomref.weight" in self.w
 
@@ -235,11 +249,16 @@ class ViSNetOracle:
         u = torch.where(loop[:, None], torch.zeros_like(ev), ev / r_safe[:, None])
         d = sphere(u, self.lmax)  # [E,S]
         C = cosine_cutoff(r, rc)  # [E]
-        means = self.w[rm + "distance_expansion.means"]
-        betas = self.w[rm + "distance_expansion.betas"]
-        t = torch.exp(-self.alpha * r)[:, None]
-        ek = torch.exp(-betas * (t - means) ** 2)
-        rbf = C[:, None] * ek  # [E,R]  utils.py:53-57
+        if self.hp["rbf_type"] == "gauss":  # utils.py:84-87: no cutoff factor
+            offset = self.w[rm + "distance_expansion.offset"]
+            coeff = self.w[rm + "distance_expansion.coeff"]
+            rbf = torch.exp(coeff * (r[:, None] - offset) ** 2)
+        else:
+            means = self.w[rm + "distance_expansion.means"]
+            betas = self.w[rm + "distance_expansion.betas"]
+            t = torch.exp(-self.alpha * r)[:, None]
+            ek = torch.exp(-betas * (t - means) ** 2)
+            rbf = C[:, None] * ek  # [E,R]  utils.py:53-57
         c.update(src=src, tgt=tgt, loop=loop, r=r, u=u, d=d, C=C, rbf=rbf, ev=ev)
 
         # embeddings (visnet_block.py:110,118-122; utils.py:296-317,331-337)
@@ -269,17 +288,17 @@ class ViSNetOracle:
             v = self._lin(xh, p + "v_proj")
             pk = self._lin(f, p + "dk_proj")
             pv = self._lin(f, p + "dv_proj")
-            dk, dv = silu(pk), silu(pv)
+            dk, dv = self.act(pk), self.act(pv)
             vp = vh @ self.w[p + "vec_proj.weight"].T  # [N,S,3H]
             vec1, vec2, vec3 = vp[..., :H], vp[..., H:2 * H], vp[..., 2 * H:]
             vec_dot = (vec1 * vec2).sum(dim=1)
             # message (visnet_block.py:276-288)
             sat = (q[tgt] * k[src] * dk).view(E, nh, hd).sum(-1)  # [E,nh]
-            a = silu(sat) * C[:, None]
+            a = self.aact(sat) * C[:, None]
             m = (v[src] * dv).view(E, nh, hd) * a[:, :, None]
             m = m.reshape(E, H)
             tpre = self._lin(m, p + "s_proj")  # [E,2H]
-            st = silu(tpre)
+            st = self.act(tpre)
             s1, s2 = st[:, :H], st[:, H:]
             mv = vh[src] * s1[:, None, :] + d[:, :, None] * s2[:, None, :]
             A = torch.zeros(N, H, dtype=dt).index_add(0, tgt, m)
@@ -297,7 +316,7 @@ class ViSNetOracle:
                 w1 = u1 - a1[:, None, :] * d[:, :, None]
                 w2 = u2 - a2[:, None, :] * d[:, :, None]
                 wd = (w1 * w2).sum(1)
-                df = silu(pf) * wd
+                df = self.act(pf) * wd
                 lc.update(wt=wt, ws=ws, pf=pf, wd=wd, df=df)
             o = self._lin(A, p + "o_proj")
             o1, o2, o3 = o[:, :H], o[:, H:2 * H], o[:, 2 * H:]
@@ -320,15 +339,15 @@ class ViSNetOracle:
         v1 = torch.sqrt((p0 * p0).sum(dim=1))  # torch.norm(dim=-2)
         v2 = vo @ self.w[on + "0.vec2_proj.weight"].T  # [N,S,H/2]
         a0 = self._lin(torch.cat([xo, v1], dim=-1), on + "0.update_net.0")
-        u0 = self._lin(silu(a0), on + "0.update_net.2")  # [N,H]
+        u0 = self._lin(self.act(a0), on + "0.update_net.2")  # [N,H]
         h2 = H // 2
         xs, gate = u0[:, :h2], u0[:, h2:]
         vec1o = gate[:, None, :] * v2
-        x1 = silu(xs)
+        x1 = self.act(xs)
         p1 = vec1o @ self.w[on + "1.vec1_proj.weight"].T  # [N,S,H/2]
         v1b = torch.sqrt((p1 * p1).sum(dim=1))
         a1b = self._lin(torch.cat([x1, v1b], dim=-1), on + "1.update_net.0")
-        u1b = self._lin(silu(a1b), on + "1.update_net.2")  # [N,2]
+        u1b = self._lin(self.act(a1b), on + "1.update_net.2")  # [N,2]
         y = u1b[:, 0:1]
         y = y * self.w["std"]
         if self.has_atomref:
@@ -372,7 +391,7 @@ class ViSNetOracle:
 
         # ---- read-out ----
         g_h1 = w["std"] * w[on + "1.update_net.2.weight"][0][None, :].expand(N, h2)
-        g_a1 = g_h1 * dsilu(c["a1b"])
+        g_a1 = g_h1 * self.dact(c["a1b"])
         g_cat1 = g_a1 @ w[on + "1.update_net.0.weight"]  # [N,H]
         g_x1, g_v1b = g_cat1[:, :h2], g_cat1[:, h2:]
         inv = torch.where(c["v1b"] > 0, 1.0 / c["v1b"].clamp(min=1e-300), torch.zeros_like(c["v1b"]))
@@ -382,10 +401,10 @@ class ViSNetOracle:
         xs = c["u0"][:, :h2]
         g_gate = (g_vec1o * c["v2"]).sum(1)
         g_v2 = g_vec1o * gate[:, None, :]
-        g_xs = g_x1 * dsilu(xs)
+        g_xs = g_x1 * self.dact(xs)
         g_u0 = torch.cat([g_xs, g_gate], dim=1)
         g_h0 = g_u0 @ w[on + "0.update_net.2.weight"]
-        g_a0 = g_h0 * dsilu(c["a0"])
+        g_a0 = g_h0 * self.dact(c["a0"])
         g_cat0 = g_a0 @ w[on + "0.update_net.0.weight"]  # [N,2H]
         g_xo, g_v1 = g_cat0[:, :H], g_cat0[:, H:]
         inv = torch.where(c["v1"] > 0, 1.0 / c["v1"].clamp(min=1e-300), torch.zeros_like(c["v1"]))
@@ -426,8 +445,8 @@ class ViSNetOracle:
                 a2 = (u2 * d[:, :, None]).sum(1)
                 cc = (d * d).sum(1) - 2.0  # [E]
                 wd = (u1 * u2).sum(1) + a1 * a2 * cc[:, None]
-                g_pf = g_f * wd * dsilu(pf)
-                g_wd = g_f * silu(pf)
+                g_pf = g_f * wd * self.dact(pf)
+                g_wd = g_f * self.act(pf)
                 g_u1 = g_wd[:, None, :] * (u2 + (a2 * cc[:, None])[:, None, :] * d[:, :, None])
                 g_u2 = g_wd[:, None, :] * (u1 + (a1 * cc[:, None])[:, None, :] * d[:, :, None])
                 g_wt = torch.zeros(N, S, H, dtype=dt).index_add(0, tgt, g_u1)
@@ -438,33 +457,33 @@ class ViSNetOracle:
                 g_pe_f = g_pf
                 lb.update(g_wt=g_wt, g_ws=g_ws, g_pf=g_pf)
             # vector messages
-            st = silu(lc["tpre"])
+            st = self.act(lc["tpre"])
             s1, s2 = st[:, :H], st[:, H:]
             gV = g_vec[tgt]  # [E,S,H]
             g_s1 = (gV * vh[src]).sum(1)
             g_s2 = (gV * d[:, :, None]).sum(1)
             g_d += (gV * s2[:, None, :]).sum(-1)
             g_vh = g_vh.index_add(0, src, gV * s1[:, None, :])
-            g_t = torch.cat([g_s1, g_s2], dim=1) * dsilu(lc["tpre"])
+            g_t = torch.cat([g_s1, g_s2], dim=1) * self.dact(lc["tpre"])
             g_m = g_t @ w[pfx + "s_proj.weight"] + g_A[tgt]
             lb.update(g_t=g_t, g_m=g_m)
             # attention
             q, k, v = lc["q"], lc["k"], lc["v"]
-            dk, dv = silu(lc["pk"]), silu(lc["pv"])
+            dk, dv = self.act(lc["pk"]), self.act(lc["pv"])
             a = lc["a"]
             aH = a[:, :, None].expand(E, nh, hd).reshape(E, H)
             g_v_e = g_m * dv * aH
             g_dv = g_m * v[src] * aH
             g_a = (g_m * v[src] * dv).view(E, nh, hd).sum(-1)
             sat = lc["sat"]
-            g_sat = g_a * dsilu(sat) * C[:, None]
-            g_C += (g_a * silu(sat)).sum(-1)
+            g_sat = g_a * self.daact(sat) * C[:, None]
+            g_C += (g_a * self.aact(sat)).sum(-1)
             gsH = g_sat[:, :, None].expand(E, nh, hd).reshape(E, H)
             g_q = torch.zeros(N, H, dtype=dt).index_add(0, tgt, gsH * k[src] * dk)
             g_k = torch.zeros(N, H, dtype=dt).index_add(0, src, gsH * q[tgt] * dk)
             g_vn = torch.zeros(N, H, dtype=dt).index_add(0, src, g_v_e)
-            g_pk = gsH * q[tgt] * k[src] * dsilu(lc["pk"])
-            g_pv = g_dv * dsilu(lc["pv"])
+            g_pk = gsH * q[tgt] * k[src] * self.dact(lc["pk"])
+            g_pv = g_dv * self.dact(lc["pv"])
             lb.update(g_sat=g_sat, g_q=g_q, g_k=g_k, g_v=g_vn, g_pk=g_pk, g_pv=g_pv)
             g_f = g_f + g_pk @ w[pfx + "dk_proj.weight"] + g_pv @ w[pfx + "dv_proj.weight"]
             if not last:
@@ -492,13 +511,18 @@ class ViSNetOracle:
         b.update(g_x_emb=g_xe, g_rbf=g_rbf, g_d=g_d, g_C=g_C, g_n=g_n, g_phi=g_phi, g_psi=g_psi)
 
         # ---- geometry ----
-        means = w[rm + "distance_expansion.means"]
-        betas = w[rm + "distance_expansion.betas"]
-        tt = torch.exp(-self.alpha * r)[:, None]
-        ek = torch.exp(-betas * (tt - means) ** 2)
         dC = dcosine_cutoff(r, rc)
-        dek = 2.0 * self.alpha * betas * tt * (tt - means) * ek
-        drbf = dC[:, None] * ek + C[:, None] * dek
+        if self.hp["rbf_type"] == "gauss":
+            offset, coeff = w[rm + "distance_expansion.offset"], w[rm + "distance_expansion.coeff"]
+            dr = r[:, None] - offset
+            drbf = 2.0 * coeff * dr * torch.exp(coeff * dr ** 2)
+        else:
+            means = w[rm + "distance_expansion.means"]
+            betas = w[rm + "distance_expansion.betas"]
+            tt = torch.exp(-self.alpha * r)[:, None]
+            ek = torch.exp(-betas * (tt - means) ** 2)
+            dek = 2.0 * self.alpha * betas * tt * (tt - means) * ek
+            drbf = dC[:, None] * ek + C[:, None] * dek
         g_r = (g_rbf * drbf).sum(-1) + g_C * dC
         g_u = sphere_vjp(u, g_d, self.lmax)
         rinv = torch.where(loop, torch.zeros_like(r), 1.0 / torch.where(loop, torch.ones_like(r), r))

@@ -61,3 +61,104 @@ def test_thermostat_reaches_target_temperature_and_keeps_com(lib_built):
         md3.step()
     assert (md2.x == md3.x).all()
     _ = com0
+
+
+def _restraints(rng, n, pos):
+    from ai2bmd_amd.md import Hookean
+
+    cons = []
+    for i in rng.choice(n, size=40, replace=False):          # position restraints, some with a dead zone
+        cons.append(Hookean(a1=int(i), a2=pos[i] + rng.normal(0, 0.3, 3), k=float(rng.uniform(0.1, 3.0)),
+                            rt=float(rng.choice([0.0, 0.2]))))
+    heavy = rng.choice(n, size=25, replace=False)
+    for i in heavy:                                           # bond restraints; atom `hub` carries several
+        j = int((i + 1 + rng.integers(n - 1)) % n)
+        cons.append(Hookean(a1=int(i), a2=j, k=float(rng.uniform(0.5, 5.0)), rt=float(rng.uniform(0.5, 2.5))))
+    hub = int(heavy[0])
+    for j in rng.choice([a for a in range(n) if a != hub], size=3, replace=False):
+        cons.append(Hookean(a1=int(j), a2=hub, k=1.3, rt=0.9))
+    return cons
+
+
+def test_hookean_restraints_match_torch_restatement(lib_built):
+    """Hookean point / pair springs with thresholds (simulator.py:139-180): forces and energy of the HIP per-atom
+    lists against the torch loop, on the start geometry (vsn_md_restrain) and after steps (inside half2)."""
+    from ai2bmd_amd.md import Langevin, LangevinHIP, hookean_forces
+
+    rng = np.random.default_rng(4)
+    n = 175
+    numbers = rng.choice([1, 6, 7, 8, 16], size=n)
+    pos = (rng.standard_normal((n, 3)) * 3).astype(np.float32)
+    cons = _restraints(rng, n, pos.astype(np.float64))
+
+    def zero(x):
+        return torch.zeros((), device=x.device), torch.zeros_like(x)
+
+    b = LangevinHIP(numbers, pos, zero, "cuda:0", temperature_K=0.0, seed=1)
+    b.set_constraints(cons)
+    torch.cuda.synchronize()
+    E_t, F_t = hookean_forces(torch.as_tensor(pos, dtype=torch.float64), cons)
+    np.testing.assert_allclose(b.F.cpu().numpy(), F_t.numpy(), rtol=0, atol=2e-5)
+    assert abs(float(b.E) - float(E_t)) < 1e-4 * max(1.0, float(E_t))
+    # the same restraints drive both integrators to the same trajectory (T = 0: no noise)
+    a = Langevin(numbers, pos, zero, "cuda:0", temperature_K=0.0, seed=1)
+    a.set_constraints(cons)
+    for _ in range(40):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(b.x.cpu().numpy(), a.x.cpu().numpy(), rtol=0, atol=5e-5)
+    np.testing.assert_allclose(b.F.cpu().numpy(), a.F.cpu().numpy(), rtol=0, atol=5e-5)
+    assert abs(float(b.E) - float(a.E)) < 1e-4 * max(1.0, abs(float(a.E)))
+    # bit-reproducible (per-atom lists, no atomics)
+    c = LangevinHIP(numbers, pos, zero, "cuda:0", temperature_K=0.0, seed=1)
+    c.set_constraints(cons)
+    for _ in range(40):
+        c.step()
+    assert torch.equal(c.x, b.x) and torch.equal(c.F, b.F)
+
+
+def test_energy_and_forces_include_the_tether_in_both_integrators(lib_built):
+    from ai2bmd_amd.md import Langevin, LangevinHIP
+
+    rng = np.random.default_rng(5)
+    numbers = rng.choice([1, 6, 8], size=60)
+    pos = rng.standard_normal((60, 3)).astype(np.float32)
+    a = Langevin(numbers, pos, harmonic(1.5), "cuda:0", temperature_K=0.0, seed=2, tether_k=0.9)
+    b = LangevinHIP(numbers, pos, harmonic(1.5), "cuda:0", temperature_K=0.0, seed=2, tether_k=0.9)
+    v0 = torch.randn(60, 3, generator=torch.Generator().manual_seed(1)).to("cuda:0") * 0.05
+    a.v, b.v = v0.clone(), v0.clone()
+    for _ in range(10):
+        a.step()
+        b.step()
+    torch.cuda.synchronize()
+    assert abs(float(a.E) - float(b.E)) < 1e-4 * max(1.0, abs(float(a.E)))
+    np.testing.assert_allclose(b.F.cpu().numpy(), a.F.cpu().numpy(), rtol=0, atol=2e-5)
+    assert float(b.E) > float(b.E_model)  # the restraint energy is in E
+
+
+def test_observers_preequilibration_and_runaway_guard(lib_built):
+    """attach(fn, interval) / run(steps) like ASE's MolecularDynamics; the five restrained pre-equilibration stages
+    (simulator.py:139-166); the temperature-runaway guard of the energy observer (utils/utils.py:143-159)."""
+    from ai2bmd_amd.md import KB, LangevinHIP, TemperatureRunawayError
+
+    rng = np.random.default_rng(6)
+    n = 120
+    numbers = rng.choice([1, 6, 7, 8], size=n)
+    pos = (rng.standard_normal((n, 3)) * 4).astype(np.float32)
+    md = LangevinHIP(numbers, pos, harmonic(0.0), "cuda:0", temperature_K=300.0, friction_per_fs=0.02, seed=9)
+    seen, snaps = [], []
+    md.attach(lambda: seen.append(md.nsteps), interval=5)
+    md.attach(lambda: snaps.append(md.x.clone()), interval=10)      # trajectory frames stay in HBM
+    md.attach(lambda: md.printenergy(quiet=True), interval=5)
+    md.run(30)
+    assert seen == [5, 10, 15, 20, 25, 30] and len(snaps) == 3 and snaps[0].is_cuda
+    epot, ekin, temp = md.observe()
+    assert abs(temp - 2.0 * ekin / (3 * n * KB)) < 1e-3 * temp and abs(ekin - float(0.5 * (md.m * md.v ** 2).sum())) < 1e-3
+    x_before = md.x.clone()
+    md.pre_equilibrate(list(range(n)), preeq_steps=4)
+    assert md.nsteps == 30 + 5 * 4 and md.constraints == [] and not torch.equal(md.x, x_before)
+    hot = LangevinHIP(numbers, pos, harmonic(0.0), "cuda:0", temperature_K=300.0, seed=9)
+    hot.v = hot.v * 3.0                                               # 9x the kinetic energy
+    with pytest.raises(TemperatureRunawayError):
+        hot.printenergy(quiet=True)

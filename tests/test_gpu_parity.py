@@ -175,9 +175,17 @@ def test_checkpoint_file_roundtrip(lib_built, tmp_path):
         def __len__(self):
             return len(self.numbers)
 
-    calc = ViSNetCalculator(model)
+    calc = ViSNetCalculator(model=model)
     calc.calculate(Atoms(), ["energy", "forces"], None)
     check(calc.results["energy"], calc.results["forces"], g["E_ref64"], g["F_ref64"])
+    # the reference's constructor (visnet_calculator.py:127-137): checkpoint directory + type, device from DeviceStrategy
+    from ai2bmd_amd.device_strategy import DeviceStrategy
+
+    DeviceStrategy.initialize("small-molecule", "combined", "mm", gpu_count=1, chunk_size=9999)
+    calc2 = ViSNetCalculator(str(tmp_path), "test", is_root_calc=True)
+    assert calc2.model is model and calc2.device == "cuda:0"
+    calc2.calculate(Atoms(), ["energy", "forces"], None)
+    assert (calc2.results["forces"] == calc.results["forces"]).all()
 
 
 @pytest.mark.parametrize("sizes", [[1], [2, 1, 0, 0, 3], [0, 0, 12, 0], [300], [64, 65, 1, 130]])
@@ -300,3 +308,17 @@ def test_atomref_table_shorter_than_max_z(lib_built):
     zb[0] = 25
     with pytest.raises(IndexError):
         m.dl_potential_loader(frag(zb, pos, start, end))
+
+
+def test_visnet_model_takes_a_loaded_model_like_the_reference(lib_built, tmp_path):
+    """ViSNetModel(model, device=...) (visnet_calculator.py:35): `model` = what load_model returned."""
+    from ai2bmd_amd.visnet_calculator import ViSNetModel, load_model
+    from oracle.weights import write_lightning_ckpt
+
+    g = load_golden("h64_l2_gauss")
+    sd = make_state_dict(g["hparams"], seed=g["weight_seed"])
+    path = str(tmp_path / "m.ckpt")
+    write_lightning_ckpt(path, g["hparams"], sd)
+    m = ViSNetModel(load_model(path), device="cuda:0")
+    e, f = m.dl_potential_loader(frag(g["z"], g["pos"], g["start"], g["end"]))
+    check(e, f, g["E_ref64"], g["F_ref64"])

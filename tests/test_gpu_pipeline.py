@@ -48,7 +48,7 @@ def test_chignolin_pipeline_matches_host_composition(setup):
     # host composition, reference-shaped: FragmentData -> DLBondedCalculator.calculate -> combiner
     pos = fragment_positions(plan, prot.positions).astype(np.float32)
     fd = FragmentData(plan.z, pos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
-    calc = DLBondedCalculator([model])
+    calc = DLBondedCalculator.from_models([model])
     e_dip, f_dip, e_ace, f_ace = calc.calculate(fd)
     E_h, F_h = combine_numpy(plan.n_prot, e_dip, f_dip, e_ace, f_ace, plan.select_index, plan.origin_index)
     e_all, f_all = model.dl_potential_loader(fd)
@@ -107,8 +107,8 @@ def test_two_handles_driven_from_two_threads(setup):
     other = ViSNetModel(hp, sd, device="cuda:0")
     pos = fragment_positions(plan, prot.positions).astype(np.float32)
     fd = FragmentData(plan.z, pos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
-    one = DLBondedCalculator([model]).calculate(fd)
-    two = DLBondedCalculator([model, other], chunk_atoms=120)
+    one = DLBondedCalculator.from_models([model]).calculate(fd)
+    two = DLBondedCalculator.from_models([model, other], chunk_atoms=120)
     two.set_work_partitions(fd.start, fd.end)
     assert {d for d, _, _ in two._work} == {0, 1} and len(two._work) >= 3
     for _ in range(3):

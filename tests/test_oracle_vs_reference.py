@@ -163,3 +163,109 @@ def test_live_reference_load_model_reads_our_checkpoint(tmp_path):
     E, F, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
     np.testing.assert_allclose(E_ref.detach().numpy(), E, atol=2e-4)
     np.testing.assert_allclose(F_ref.detach().numpy(), F, atol=2e-4)
+
+
+def test_reference_bonded_calculator_drives_our_seam_unchanged(lib_built):
+    """The reference's OWN Calculators/bonded.py (DLBondedCalculator.__init__/calculate/__call__, :25-123), loaded from
+    /root/reference with its absent imports stubbed, is pointed at a `get_visnet_model` that returns an object with our
+    seam's shape (`dl_potential_loader(FragmentData) -> (e[B,1], f[N,3])` numpy; here backed by the CPU oracle, the HIP
+    model needs a GPU) and at a fragment producer handing out OUR FragmentData.  It runs unchanged and its result
+    equals the mirror class's (ai2bmd_amd.bonded.DLBondedCalculator) on the same inputs."""
+    import os
+    import sys
+    import types
+
+    from ai2bmd_amd.amber import load_tables
+    from ai2bmd_amd.bonded import DLBondedCalculator as Mirror
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+    from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, combine_host, fragment_positions
+    from ai2bmd_amd.hydrogen import build_hydrogen_plan
+    from conftest import GOLDEN
+    from oracle.hydrogen_oracle import HydrogenOracle
+
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    sd = make_state_dict(hp, seed=33)
+    oracle = ViSNetOracle(hp, sd, torch.float32)
+    calls = []
+
+    class OracleSeam:  # the shape of ai2bmd_amd.visnet_calculator.ViSNetModel
+        implemented_properties = ["energy", "forces"]
+
+        def __init__(self, device):
+            self.device = device
+
+        def dl_potential_loader(self, frag_data):
+            calls.append((self.device, len(frag_data)))
+            E, F, _ = oracle.energy_forces(frag_data.z, frag_data.pos, frag_data.start, frag_data.end)
+            return E.astype(np.float32).reshape(-1, 1), F.astype(np.float32)
+
+    d = np.load(os.path.join(GOLDEN, "protein_chig.npz"))
+    prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+    plan = build_plan(prot)
+    hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(GOLDEN, "amber_tables.npz")))
+
+    class Fragmenter:  # DistanceFragment.get_fragments on the host (the HIP one needs a GPU)
+        def get_fragments(self, p):
+            pos = HydrogenOracle(hplan).relax(fragment_positions(plan, p.positions).astype(np.float32))
+            ace = hplan.alias >= 0
+            pos[ace] = pos[hplan.alias[ace]]
+            return FragmentData(plan.z, pos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
+
+    stubs = (("ase", {"Atoms": object}),)
+    ref_fragment = _load_reference_module("ref_fragment2", "AIMD/fragment.py", stubs=stubs)
+    ref_ds = _load_reference_module(
+        "ref_device_strategy2", "Calculators/device_strategy.py",
+        stubs=(("AIMD", {}), ("AIMD.fragment", {"FragmentInfo": object}), ("utils", {}),
+               ("utils.system", {"get_physical_core_count": lambda: 8})))
+    ref_comb = _load_reference_module("ref_combiner2", "Calculators/combiner.py")
+    saved = {k: sys.modules.get(k) for k in ("AIMD", "AIMD.arguments", "AIMD.fragment", "AIMD.protein",
+                                              "Calculators", "Calculators.combiner", "Calculators.device_strategy",
+                                              "Calculators.visnet_calculator", "Fragmentation", "utils", "utils.utils")}
+    try:
+        def mod(name, **attrs):
+            m = types.ModuleType(name)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+            return m
+
+        mod("AIMD", arguments=mod("AIMD.arguments"))
+        mod("AIMD.fragment", FragmentData=ref_fragment.FragmentData)
+        mod("AIMD.protein", Protein=object)
+        mod("Calculators")
+        mod("Calculators.combiner", DipeptideBondedCombiner=ref_comb.DipeptideBondedCombiner)
+        mod("Calculators.device_strategy", DeviceStrategy=ref_ds.DeviceStrategy)
+        mod("Calculators.visnet_calculator", ViSNetModelLike=object,
+            get_visnet_model=lambda model_path, device: OracleSeam(device))
+        mod("Fragmentation", DistanceFragment=Fragmenter)
+        mod("utils")
+        mod("utils.utils", numpy_to_torch=lambda a, device=None: torch.as_tensor(np.asarray(a)))
+        ref_bonded = _load_reference_module("ref_bonded", "Calculators/bonded.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    DS = ref_ds.DeviceStrategy
+    DS._gpu_count, DS._bonded_devices, DS._default_device, DS._chunk_size = 0, ["cpu", "cpu"], "cpu", 120
+    DS.set_work_partitions(plan.start.tolist(), plan.end.tolist())
+    calc = ref_bonded.DLBondedCalculator("/ckpts", "test")            # the reference's own constructor
+    assert [m.device for m in calc.models] == ["cpu", "cpu"]
+    prot.select_index = torch.as_tensor(plan.select_index)           # what DistanceFragment.fragment leaves on prot
+    prot.origin_index = torch.as_tensor(plan.origin_index)
+    E_ref, F_ref = calc(prot)                                         # the reference's own __call__
+    assert len(calls) == len(DS.get_work_partitions()) >= 4 and {c[0] for c in calls} == {"cpu"}
+    # the mirror class on the same seam objects, fragmenter and partitions
+    mirror = Mirror.from_models([OracleSeam("a"), OracleSeam("b")], chunk_atoms=120, fragment_method=Fragmenter())
+    prot.select_index, prot.origin_index = plan.select_index, plan.origin_index
+    E_m, F_m = mirror(prot)
+    assert mirror._work == [tuple(t) for t in DS.get_work_partitions()]
+    np.testing.assert_allclose(np.asarray(F_ref), F_m, rtol=0, atol=1e-6)
+    assert abs(float(E_ref) - float(E_m)) < 1e-4
+    # and both equal the straight evaluation of the whole batch + host recombination
+    fd = Fragmenter().get_fragments(prot)
+    E_all, F_all, _ = oracle.energy_forces(fd.z, fd.pos, fd.start, fd.end)
+    E_h, F_h = combine_host(plan, E_all.reshape(-1, 1), F_all)
+    np.testing.assert_allclose(F_m, F_h, rtol=0, atol=2e-5)
+    assert abs(float(E_m) - E_h) < 2e-4 * max(1.0, abs(E_h))

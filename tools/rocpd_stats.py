@@ -92,7 +92,38 @@ def gaps(path, lo=0.3, hi=0.6):
         print(f"  p{int(q * 100):02d} {g[int(q * (n - 1))] / 1e3:.2f} us")
 
 
+def timeline(path, anchor="k_build_fragments", which=-3):
+    """one MD step as a kernel sequence: offset of every dispatch from the step's first kernel (`anchor`),
+    duration, queue (stream) and grid - the `which`-th occurrence of the anchor (negative = from the end)"""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    disp = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    sym = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    scols = [r[1] for r in cur.execute(f"pragma table_info({sym})")]
+    dcols = [r[1] for r in cur.execute(f"pragma table_info({disp})")]
+    name_col = "kernel_name" if "kernel_name" in scols else ("display_name" if "display_name" in scols else "name")
+    gx = "grid_size_x" if "grid_size_x" in dcols else "grid_x"
+    qcol = "queue_id" if "queue_id" in dcols else ("stream_id" if "stream_id" in dcols else None)
+    q = (f"select d.start, d.end, s.{name_col}, d.{gx}, {('d.' + qcol) if qcol else '0'} from {disp} d "
+         f"join {sym} s on d.kernel_id = s.id order by d.start")
+    rows = list(cur.execute(q))
+    idx = [i for i, r in enumerate(rows) if anchor in r[2]]
+    a, b = idx[which], idx[which + 1]
+    t0 = rows[a][0]
+    print("offset_us,dur_us,gap_before_us,queue,grid_x,kernel")
+    prev_end = t0
+    for st, en, n, g, qd in rows[a:b]:
+        short = n.split("(")[0].replace("_ZN3vsn", "").replace(".kd", "")[:48]
+        print(f"{(st - t0) / 1e3:.1f},{(en - st) / 1e3:.1f},{(st - prev_end) / 1e3:.1f},{qd},{g},{short}")
+        prev_end = max(prev_end, en)
+    print(f"# step span {(rows[b][0] - t0) / 1e3:.1f} us, {b - a} dispatches")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[2] == "--timeline":
+        timeline(sys.argv[1], *sys.argv[3:4])
+        sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
         gaps(sys.argv[1], *[float(v) for v in sys.argv[3:5]])
         sys.exit(0)
