@@ -26,19 +26,20 @@
 
 namespace vsn {
 
-// SILU: apply silu() to A on its way into LDS (one product of the read-out head); a template parameter so that
-// the ~250 VALU instructions of the exact sigmoid are not sitting in the k-loop of every other product.
-template <int BM, int BN, int WM, int WN, bool DB, bool SILU = false>
+// SILU: apply the activation to A on its way into LDS (one product of the read-out head); a template parameter so
+// that the ~250 VALU instructions of the exact sigmoid are not sitting in the k-loop of every other product
+// (1 = silu, 2 = any kind of the reference's table, carried in flags bits 8..).
+template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32, int PF = 1>
 __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
                                           int ldb, float* __restrict__ C, int ldc,
                                           const float* __restrict__ bias, int M, const int* __restrict__ Mptr,
                                           int Nc, int K, int flags, int ksplit, float* __restrict__ part,
                                           int block_id, float* __restrict__ smem) {
-  constexpr int BK = 32;
   constexpr int LS = BK + 4;  // padded LDS row stride (floats)
+  constexpr int C4 = BK / 4;  // 16-byte chunks per tile row
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int LA = BM / 32, LB = BN / 32;  // 16-byte loads per thread per k-tile
+  constexpr int LA = BM * C4 / 256, LB = BN * C4 / 256;  // 16-byte loads per thread per k-tile
   constexpr int STAGE = (BM + BN) * LS;
 
   int Meff = M;
@@ -61,38 +62,41 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
-  constexpr bool silu_a = SILU;
-  const int akind = flags >> 8;
+  constexpr bool silu_a = SILU != 0;  // 1: silu (folds to the branch-free form), 2: kind from flags bits 8..
+  const int akind = SILU == 2 ? (flags >> 8) : VSN_ACT_SILU;
   // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce)
   const int nkt_all = K / BK;
   const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
   const int nkt = kt1 - kt0;
   const int kbase = kt0 * BK;
 
-  f32x4 ra[LA], rb[LB];
-#define VSN_GLOAD(k0)                                                                        \
+  // PF = global-load prefetch depth of the double-buffered pipeline, in k-tiles held in registers (1 or 2)
+  f32x4 rra[PF][LA], rrb[PF][LB];
+#define VSN_GLOAD(k0) VSN_GLOAD_S(0, k0)
+#define VSN_SSTORE(buf) VSN_SSTORE_S(0, buf)
+#define VSN_GLOAD_S(SET, k0)                                                                   \
   {                                                                                          \
     _Pragma("unroll") for (int it = 0; it < LA; ++it) {                                      \
       const int f_ = tid + it * 256;                                                         \
-      const int r_ = f_ >> 3, c4_ = f_ & 7;                                                  \
+      const int r_ = f_ / C4, c4_ = f_ % C4;                                                  \
       int gr_ = row0 + r_;                                                                   \
       gr_ = gr_ < Meff ? gr_ : Meff - 1; /* clamp: rows >= Meff are never stored */          \
-      ra[it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4);      \
+      rra[SET][it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4); \
     }                                                                                        \
     _Pragma("unroll") for (int it = 0; it < LB; ++it) {                                      \
       const int f_ = tid + it * 256;                                                         \
-      const int r_ = f_ >> 3, c4_ = f_ & 7;                                                  \
-      rb[it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r_) * ldb + (k0) + c4_ * 4); \
+      const int r_ = f_ / C4, c4_ = f_ % C4;                                                  \
+      rrb[SET][it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r_) * ldb + (k0) + c4_ * 4); \
     }                                                                                        \
   }
-#define VSN_SSTORE(buf)                                                       \
+#define VSN_SSTORE_S(SET, buf)                                                \
   {                                                                           \
     float* As_ = smem + (buf) * STAGE;                                        \
     float* Bs_ = As_ + BM * LS;                                               \
     _Pragma("unroll") for (int it = 0; it < LA; ++it) {                       \
       const int f_ = tid + it * 256;                                          \
-      const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
-      f32x4 v_ = ra[it];                                                      \
+      const int r_ = f_ / C4, c4_ = f_ % C4;                                   \
+      f32x4 v_ = rra[SET][it];                                                \
       if (silu_a) { /* activation kind (VSN_ACT_*) rides in flags bits 8.. */  \
         v_.x = act_f(akind, v_.x);                                            \
         v_.y = act_f(akind, v_.y);                                            \
@@ -103,8 +107,8 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     }                                                                         \
     _Pragma("unroll") for (int it = 0; it < LB; ++it) {                       \
       const int f_ = tid + it * 256;                                          \
-      const int r_ = f_ >> 3, c4_ = f_ & 7;                                   \
-      *reinterpret_cast<f32x4*>(Bs_ + r_ * LS + c4_ * 4) = rb[it];            \
+      const int r_ = f_ / C4, c4_ = f_ % C4;                                   \
+      *reinterpret_cast<f32x4*>(Bs_ + r_ * LS + c4_ * 4) = rrb[SET][it];      \
     }                                                                         \
   }
 
@@ -139,7 +143,11 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     VSN_SSTORE(0);
     {
       const int kn = (1 < nkt ? 1 : 0) * BK + kbase;
-      VSN_GLOAD(kn);
+      VSN_GLOAD(kn);  // set 0 <- tile 1
+    }
+    if constexpr (PF == 2) {
+      const int kn = (2 < nkt ? 2 : nkt - 1) * BK + kbase;
+      VSN_GLOAD_S(PF - 1, kn);  // set 1 <- tile 2
     }
     __syncthreads();
   } else {
@@ -161,7 +169,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     __builtin_amdgcn_s_setprio(2);  // lab: favour waves inside their MFMA block
 #endif
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 a[MI], b[NI];
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -184,12 +192,28 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 #elif VSN_LAB_PRIO == 1
     __builtin_amdgcn_s_setprio(3);  // lab: favour waves in their LDS-store / prefetch / barrier phase
 #endif
-    if (DB && kt + 1 < nkt) {
+    if (DB && PF == 1 && kt + 1 < nkt) {
       // tile kt+1 (in registers) -> the other LDS buffer (last read in iteration kt-1, a barrier ago)
       VSN_SSTORE((kt + 1) & 1);
       const int kn = (kt + 2 < nkt ? kt + 2 : kt + 1) * BK + kbase;
       VSN_GLOAD(kn);
       __builtin_amdgcn_sched_barrier(0);  // issue the prefetch before the barrier / next MFMA block
+    }
+    if constexpr (DB && PF == 2) {
+      // two tiles in flight: set (kt & 1) holds tile kt+1 (loaded two iterations ago), the other set tile kt+2;
+      // after the store the freed set fetches tile kt+3 - a load now has two MFMA blocks to land, which a workgroup
+      // that is alone on its CU (grid tails, launches of ~3 tiles per CU) needs
+      if (kt + 1 < nkt) {
+        const int kn = (kt + 3 < nkt ? kt + 3 : nkt - 1) * BK + kbase;
+        if ((kt & 1) == 0) {
+          VSN_SSTORE_S(0, (kt + 1) & 1);
+          VSN_GLOAD_S(0, kn);
+        } else {
+          VSN_SSTORE_S(PF - 1, (kt + 1) & 1);
+          VSN_GLOAD_S(PF - 1, kn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
 #if VSN_LAB_PRIO == 1
@@ -220,23 +244,26 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
     }
 #undef VSN_GLOAD
 #undef VSN_SSTORE
+#undef VSN_GLOAD_S
+#undef VSN_SSTORE_S
 }
 
-template <int BM, int BN, int WM, int WN, bool DB, bool SILU = false>
+template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32, int PF = 1>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, int M,
                                               const int* __restrict__ Mptr, int Nc, int K, int flags,
                                               int ksplit, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * 36];
-  gemm_body<BM, BN, WM, WN, DB, SILU>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * (BK + 4)];
+  gemm_body<BM, BN, WM, WN, DB, SILU, BK, PF>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
                                       (int)blockIdx.x, smem);
 }
 
 // Several independent products in ONE launch (64x64 tiles): block -> (problem, tile).  Used for the
 // per-layer groups {qkv, vector projections, edge linears}, {s_proj, o_proj}, {dX products}: on a
 // single-protein MD step the small members (N = a few hundred rows) cannot fill 256 CUs alone.
+template <int PF>
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 36];
   int b = (int)blockIdx.x, p = 0;
@@ -247,8 +274,8 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
       p = q + 1;
     }
   const GemmDesc& d = g.p[p];
-  gemm_body<64, 64, 2, 2, true>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K, d.flags,
-                                d.ksplit, d.part, b, smem);
+  gemm_body<64, 64, 2, 2, true, 0, 32, PF>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
+                                           d.flags, d.ksplit, d.part, b, smem);
 }
 
 // split-K epilogue: C (+)= sum_s part[s] (+ bias), fixed summation order
@@ -277,6 +304,7 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 int g_splitk_tiles = 400;   // split-K only below this many output tiles (env VSN_SPLITK_TILES; swept on Chignolin: 0:297, 200:306, 400:306, 768:301, 1200:289 steps/s)
 int g_gemm_force = 0;     // micro-benchmark aid (env VSN_GEMM_FORCE): force an experimental tile variant
+int g_gemm_pf = 1;  // global-load prefetch depth of the grouped 64x64 kernel (env VSN_GEMM_PF: 1 | 2)
 int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
@@ -295,6 +323,8 @@ static bool gemm_env_init() {
   if (e) g_gemm_db128 = atoi(e);
   e = getenv("VSN_SPLITK_TILES");
   if (e) g_splitk_tiles = atoi(e);
+  e = getenv("VSN_GEMM_PF");
+  if (e) g_gemm_pf = atoi(e);
   e = getenv("VSN_GEMM_FORCE");
   if (e) g_gemm_force = atoi(e);
   return true;
@@ -352,12 +382,20 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
 #undef VSN_TRY
   }
   if (flags & 2) {  // silu(A): its own instantiations, no split-K
-    if ((Nc % 64) == 0)
-      hipLaunchKernelGGL((k_gemm<64, 64, 2, 2, true, true>), dim3(((M + 63) / 64) * (Nc / 64)), dim3(256), 0, st, A, lda,
-                         Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, 1, nullptr);
+    const bool gen = (flags >> 8) != VSN_ACT_SILU;
+    const dim3 g64(((M + 63) / 64) * (Nc / 64)), g32(((M + 127) / 128) * (Nc / 32));
+    if ((Nc % 64) == 0 && !gen)
+      hipLaunchKernelGGL((k_gemm<64, 64, 2, 2, true, 1>), g64, dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M, Mptr,
+                         Nc, K, flags, 1, nullptr);
+    else if ((Nc % 64) == 0)
+      hipLaunchKernelGGL((k_gemm<64, 64, 2, 2, true, 2>), g64, dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M, Mptr,
+                         Nc, K, flags, 1, nullptr);
+    else if (!gen)
+      hipLaunchKernelGGL((k_gemm<128, 32, 4, 1, true, 1>), g32, dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M, Mptr,
+                         Nc, K, flags, 1, nullptr);
     else
-      hipLaunchKernelGGL((k_gemm<128, 32, 4, 1, true, true>), dim3(((M + 127) / 128) * (Nc / 32)), dim3(256), 0, st, A,
-                         lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, 1, nullptr);
+      hipLaunchKernelGGL((k_gemm<128, 32, 4, 1, true, 2>), g32, dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M, Mptr,
+                         Nc, K, flags, 1, nullptr);
     return 0;
   }
   const int variant = gemm_variant(M, Nc);
@@ -477,7 +515,10 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     }
     g.p[g.n++] = d;
   }
-  if (g.n > 0) hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
+  if (g.n > 0) {
+    if (g_gemm_pf == 2) hipLaunchKernelGGL(k_gemm_group<2>, dim3(grid), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(k_gemm_group<1>, dim3(grid), dim3(256), 0, st, g);
+  }
   for (int i = 0; i < nred; ++i) {
     const GemmDesc& d = red[i];
     long long n4 = (long long)d.M * (d.Nc / 4);

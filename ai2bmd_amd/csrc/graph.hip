@@ -9,8 +9,8 @@
 // torch_cluster's CUDA kernel produces), at most max_nb sources per target
 // keeping the lowest indices, self loops kept; plus the same edge set grouped
 // by source (perm/colptr) for the reverse pass' deterministic segmented sums.
-// One workgroup per fragment; fragments are tiny (<= 44 atoms in AI2BMD) but
-// any size up to VSN_MAX_FRAG_ATOMS works (whole-molecule mode, B = 1).
+// Fragments of AI2BMD are tiny (<= 44 atoms): one workgroup per fragment, everything in LDS.  Batches holding a
+// larger fragment (whole-molecule mode, B = 1, up to VSN_MAX_FRAG_ATOMS) take the node-parallel passes below.
 #include "common.h"
 #include "kernels.h"
 
@@ -76,83 +76,6 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, int*
   }
 }
 
-// pass 2: fill src/tgt in CSR-by-target order, then the by-source view.
-__global__ void k_graph_fill(const float* __restrict__ pos, const int* __restrict__ fstart,
-                             const int* __restrict__ fend, const int* __restrict__ rowptr, int* __restrict__ src,
-                             int* __restrict__ tgt, int* __restrict__ colptr, int* __restrict__ perm, float rc2,
-                             int max_nb) {
-  extern __shared__ int sm[];  // outdeg / prefix per local node (n ints) + 1
-  const int b = blockIdx.x;
-  const int s = fstart[b], n = fend[b] - s;
-  if (n <= 0) {
-    return;
-  }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    int e = rowptr[s + i];
-    int cnt = 0;
-    for (int j = 0; j < n && cnt < max_nb; ++j)
-      if (dist2(pos, s + j, s + i) < rc2) {
-        src[e] = s + j;
-        tgt[e] = s + i;
-        ++e;
-        ++cnt;
-      }
-  }
-  __threadfence_block();
-  __syncthreads();
-  // out-degree of every source j: targets i that kept j
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    int cnt = 0;
-    for (int i = 0; i < n; ++i) {
-      if (!(dist2(pos, s + j, s + i) < rc2)) continue;
-      int lo = rowptr[s + i], hi = rowptr[s + i + 1];
-      // row is ascending in source: binary search for s+j
-      int key = s + j;
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        int v = src[mid];
-        if (v < key)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      if (lo < rowptr[s + i + 1] && src[lo] == key) ++cnt;
-    }
-    sm[j] = cnt;
-  }
-  __syncthreads();
-  // exclusive scan of sm[0..n) (fragments are small: serial by one thread is fine
-  // up to a few thousand atoms; chunked for larger)
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int j = 0; j < n; ++j) {
-      int v = sm[j];
-      sm[j] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  const int ebase = rowptr[s];
-  for (int j = threadIdx.x; j < n; j += blockDim.x) {
-    int out = ebase + sm[j];
-    colptr[s + j] = out;
-    for (int i = 0; i < n; ++i) {
-      if (!(dist2(pos, s + j, s + i) < rc2)) continue;
-      int lo = rowptr[s + i], hi = rowptr[s + i + 1];
-      int key = s + j;
-      while (lo < hi) {
-        int mid = (lo + hi) >> 1;
-        int v = src[mid];
-        if (v < key)
-          lo = mid + 1;
-        else
-          hi = mid;
-      }
-      if (lo < rowptr[s + i + 1] && src[lo] == key) perm[out++] = lo;
-    }
-  }
-}
-
 // Small-fragment variant of pass 2 (n <= 64, every AI2BMD fragment): one wave per fragment,
 // positions and the dense n x n edge-id matrix live in LDS, so the by-source view needs no
 // searches: thread j just walks column j in ascending target order.
@@ -210,6 +133,90 @@ __global__ __launch_bounds__(64) void k_graph_fill_small(const float* __restrict
       if (e >= 0) perm[out++] = e;
     }
   }
+}
+
+// ---- fragments larger than a wavefront (whole-molecule mode, `--mode visnet`: ONE fragment of 10^3..10^4 atoms,
+// Calculators/visnet_calculator.py:139-155).  Same edges, same order, same truncation rule as above, but one THREAD
+// per node over as many workgroups as the batch needs instead of one 64-thread workgroup per fragment: every pass
+// is n threads x n ascending candidates (all lanes of a wave read the same candidate position: a broadcast), the
+// out-degree prefix is a global scan (edges never leave their fragment, so the global exclusive scan of the
+// out-degrees IS colptr).
+__device__ __forceinline__ int frag_of(const int* __restrict__ fend, int B, int i) {
+  int lo = 0, hi = B - 1;  // first fragment whose end is > i
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (fend[mid] > i) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ void k_graph_count_big(const float* __restrict__ pos, const long long* __restrict__ z64,
+                                  const int* __restrict__ fstart, const int* __restrict__ fend, int B, int N,
+                                  int* __restrict__ deg, int* __restrict__ zi, float rc2, int max_nb, int z_limit,
+                                  int* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int b = frag_of(fend, B, i);
+  const int s = fstart[b], e = fend[b];
+  int cnt = 0;
+  for (int j = s; j < e && cnt < max_nb; ++j)
+    if (dist2(pos, j, i) < rc2) ++cnt;
+  deg[i] = cnt;
+  const long long zv = z64[i];
+  const bool bad = zv < 0 || zv >= (long long)z_limit;
+  if (bad) atomicOr(status, 1);
+  zi[i] = bad ? 0 : (int)zv;
+}
+
+__global__ void k_graph_fill_big(const float* __restrict__ pos, const int* __restrict__ fstart,
+                                 const int* __restrict__ fend, int B, int N, const int* __restrict__ rowptr,
+                                 int* __restrict__ src, int* __restrict__ tgt, float rc2, int max_nb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int b = frag_of(fend, B, i);
+  const int s = fstart[b], e = fend[b];
+  int out = rowptr[i], cnt = 0;
+  for (int j = s; j < e && cnt < max_nb; ++j)
+    if (dist2(pos, j, i) < rc2) {
+      src[out] = j;
+      tgt[out] = i;
+      ++out;
+      ++cnt;
+    }
+}
+
+// position of source j in target i's (ascending) row, or -1 when the truncation dropped it
+__device__ __forceinline__ int row_find(const int* __restrict__ rowptr, const int* __restrict__ src, int i, int j) {
+  int lo = rowptr[i], hi = rowptr[i + 1];
+  const int end = hi;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (src[mid] < j) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < end && src[lo] == j) ? lo : -1;
+}
+
+// FILL == false: outdeg[j] = number of targets that kept j ; FILL == true: perm[colptr[j]..] = those edges, targets ascending
+template <bool FILL>
+__global__ void k_graph_bysrc_big(const float* __restrict__ pos, const int* __restrict__ fstart,
+                                  const int* __restrict__ fend, int B, int N, const int* __restrict__ rowptr,
+                                  const int* __restrict__ src, int* __restrict__ outdeg,
+                                  const int* __restrict__ colptr, int* __restrict__ perm, float rc2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const int b = frag_of(fend, B, j);
+  const int s = fstart[b], e = fend[b];
+  int cnt = 0, out = FILL ? colptr[j] : 0;
+  for (int i = s; i < e; ++i) {
+    if (!(dist2(pos, j, i) < rc2)) continue;
+    const int at = row_find(rowptr, src, i, j);
+    if (at < 0) continue;
+    if (FILL) perm[out++] = at;
+    else ++cnt;
+  }
+  if (!FILL) outdeg[j] = cnt;
 }
 
 // per-edge geometry: one thread per (edge, rbf index); Rp = padded rbf count (multiple of 32)
@@ -352,16 +359,26 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
 
 int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.B <= 0 || a.N <= 0) return 0;
-  hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
-                     a.max_nb, a.z_limit, a.status);
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
   if (a.max_frag <= 64) {
+    hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
+                       a.max_nb, a.z_limit, a.status);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
     hipLaunchKernelGGL(k_graph_fill_small, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr, a.src,
                        a.tgt, a.colptr, a.perm, a.rc2, a.max_nb);
   } else {
-    size_t shm = (size_t)(a.max_frag + 1) * sizeof(int);
-    hipLaunchKernelGGL(k_graph_fill, dim3(a.B), dim3(64), shm, st, a.pos, a.fstart, a.fend, a.rowptr, a.src, a.tgt,
-                       a.colptr, a.perm, a.rc2, a.max_nb);
+    // a fragment larger than a wavefront somewhere in the batch: node-parallel passes (any mix of sizes)
+    const dim3 grid((a.N + 255) / 256), blk(256);
+    hipLaunchKernelGGL(k_graph_count_big, grid, blk, 0, st, a.pos, a.z64, a.fstart, a.fend, a.B, a.N, a.deg, a.zi,
+                       a.rc2, a.max_nb, a.z_limit, a.status);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
+    hipLaunchKernelGGL(k_graph_fill_big, grid, blk, 0, st, a.pos, a.fstart, a.fend, a.B, a.N, a.rowptr, a.src, a.tgt,
+                       a.rc2, a.max_nb);
+    // deg is free again: reuse it for the out-degrees, whose exclusive scan is colptr
+    hipLaunchKernelGGL(k_graph_bysrc_big<false>, grid, blk, 0, st, a.pos, a.fstart, a.fend, a.B, a.N, a.rowptr, a.src,
+                       a.deg, nullptr, nullptr, a.rc2);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.colptr, a.colptr, a.N, a.ecount);
+    hipLaunchKernelGGL(k_graph_bysrc_big<true>, grid, blk, 0, st, a.pos, a.fstart, a.fend, a.B, a.N, a.rowptr, a.src,
+                       nullptr, a.colptr, a.perm, a.rc2);
   }
   long long tot = (long long)a.Emax * a.Rp;
   int blocks = (int)((tot + 255) / 256);

@@ -26,19 +26,21 @@ __global__ void hk_norm_s(int N, int S, int C, const float* __restrict__ p, int 
 }
 
 // x1 = silu(xs) -> cat1[:, :h2] ; vec1o[s] = gate * v2[s]
+template <bool GEN>
 __global__ void hk_mid(int N, int S, int H, int act, const float* __restrict__ u0, const float* __restrict__ pv0,
                        int ldp, float* __restrict__ cat1, float* __restrict__ vec1o) {
   const int h2 = H / 2;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)N * h2) return;
   const int i = (int)(gid / h2), c = (int)(gid % h2);
-  cat1[(size_t)i * H + c] = act_f(act, u0[(size_t)i * H + c]);
+  cat1[(size_t)i * H + c] = act_f(GEN ? act : VSN_ACT_SILU, u0[(size_t)i * H + c]);
   const float gate = u0[(size_t)i * H + h2 + c];
   for (int s = 0; s < S; ++s)
     vec1o[((size_t)i * S + s) * h2 + c] = gate * pv0[((size_t)i * S + s) * ldp + H + c];
 }
 
 // y_i = std * (wb1 . silu(a1b_i) + bb1) + atomref[z_i]   (one wave per node)
+template <bool GEN>
 __global__ void hk_final(int N, int h2, int act, const float* __restrict__ a1b, const float* __restrict__ wb1, float bb1,
                          float stdv, const float* __restrict__ atomref, const int* __restrict__ zi,
                          float* __restrict__ y) {
@@ -46,7 +48,7 @@ __global__ void hk_final(int N, int h2, int act, const float* __restrict__ a1b, 
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   float acc = 0.f;
-  for (int c = lane; c < h2; c += 64) acc += act_f(act, a1b[(size_t)i * h2 + c]) * wb1[c];
+  for (int c = lane; c < h2; c += 64) acc += act_f(GEN ? act : VSN_ACT_SILU, a1b[(size_t)i * h2 + c]) * wb1[c];
   acc = wave_sum(acc);
   if (lane == 0) {
     float v = (acc + bb1) * stdv;
@@ -66,12 +68,13 @@ __global__ void hk_energy(int B, const int* __restrict__ fstart, const int* __re
 }
 
 // ---- reverse ----
+template <bool GEN>
 __global__ void hk_b_a1(int N, int h2, int act, const float* __restrict__ a1b, const float* __restrict__ wb1, float stdv,
                         float* __restrict__ g_a1) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)N * h2) return;
   const int c = (int)(gid % h2);
-  g_a1[gid] = stdv * wb1[c] * dact_f(act, a1b[gid]);
+  g_a1[gid] = stdv * wb1[c] * dact_f(GEN ? act : VSN_ACT_SILU, a1b[gid]);
 }
 
 // g_p[s] = g_v * p[s] / v   (adjoint of the 2-norm over s; 0 where v == 0 like torch.norm)
@@ -88,6 +91,7 @@ __global__ void hk_b_norm_s(int N, int S, int C, const float* __restrict__ g_cat
 }
 
 // g_gate = sum_s g_vec1o[s] v2[s] ; g_v2[s] = g_vec1o[s] gate ; g_xs = g_x1 silu'(xs)
+template <bool GEN>
 __global__ void hk_b_mid(int N, int S, int H, int act, const float* __restrict__ u0, const float* __restrict__ pv0, int ldp,
                          const float* __restrict__ g_vec1o, const float* __restrict__ g_cat1,
                          float* __restrict__ g_u0, float* __restrict__ g_pv0) {
@@ -102,16 +106,19 @@ __global__ void hk_b_mid(int N, int S, int H, int act, const float* __restrict__
     gg += gv * pv0[((size_t)i * S + s) * ldp + H + c];
     g_pv0[((size_t)i * S + s) * ldp + H + c] = gv * gate;
   }
-  g_u0[(size_t)i * H + c] = g_cat1[(size_t)i * H + c] * dact_f(act, u0[(size_t)i * H + c]);
+  g_u0[(size_t)i * H + c] = g_cat1[(size_t)i * H + c] * dact_f(GEN ? act : VSN_ACT_SILU, u0[(size_t)i * H + c]);
   g_u0[(size_t)i * H + h2 + c] = gg;
 }
 
+template <bool GEN>
 __global__ void hk_b_mul_dsilu(long long n, int act, const float* __restrict__ a, float* __restrict__ g) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= n) return;
-  g[gid] *= dact_f(act, a[gid]);
+  g[gid] *= dact_f(GEN ? act : VSN_ACT_SILU, a[gid]);
 }
 
+// activation-using head kernels: <false> = all-silu network (folds to the branch-free form), <true> = kind from D.act
+#define VSN_HK(K) hipLaunchKernelGGL((D.act == VSN_ACT_SILU ? K<false> : K<true>)
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, const float* vo,
@@ -128,13 +135,13 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
                      2 * H, H);
   rc |= launch_gemm(st, Bf.cat0, 2 * H, W.Wa0, 2 * H, Bf.a0, H, W.ba0, N, nullptr, H, 2 * H, 0);
   rc |= launch_gemm(st, Bf.a0, H, W.Wb0, H, Bf.u0, H, W.bb0, N, nullptr, H, H, 2 | (D.act << 8));
-  hipLaunchKernelGGL(hk_mid, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, D.act, Bf.u0, Bf.pv0, ldp,
+  VSN_HK(hk_mid), dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, D.act, Bf.u0, Bf.pv0, ldp,
                      Bf.cat1, Bf.vec1o);
   rc |= launch_gemm(st, Bf.vec1o, h2, W.W11, h2, Bf.p1, h2, nullptr, N * S, nullptr, h2, h2, 0);
   hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.p1, h2, Bf.cat1, H,
                      h2);
   rc |= launch_gemm(st, Bf.cat1, H, W.Wa1, H, Bf.a1b, h2, W.ba1, N, nullptr, h2, H, 0);
-  hipLaunchKernelGGL(hk_final, dim3((N + 3) / 4), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
+  VSN_HK(hk_final), dim3((N + 3) / 4), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
                      D.zi, Bf.y);
   hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
                                   W.status);
@@ -146,16 +153,16 @@ int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const He
   const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
   if (N <= 0) return 0;
   int rc = 0;
-  hipLaunchKernelGGL(hk_b_a1, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.stdv,
+  VSN_HK(hk_b_a1), dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.stdv,
                      Bf.g_a1);
   rc |= launch_gemm(st, Bf.g_a1, h2, W.Wa1T, h2, Bf.g_cat1, H, nullptr, N, nullptr, H, h2, 0);
   hipLaunchKernelGGL(hk_b_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.g_cat1, H, h2,
                      Bf.cat1, H, h2, Bf.p1, h2, Bf.g_p1, h2);
   rc |= launch_gemm(st, Bf.g_p1, h2, W.W11T, h2, Bf.g_vec1o, h2, nullptr, N * S, nullptr, h2, h2, 0);
-  hipLaunchKernelGGL(hk_b_mid, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, D.act, Bf.u0, Bf.pv0, ldp,
+  VSN_HK(hk_b_mid), dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, H, D.act, Bf.u0, Bf.pv0, ldp,
                      Bf.g_vec1o, Bf.g_cat1, Bf.g_u0, Bf.g_pv0);
   rc |= launch_gemm(st, Bf.g_u0, H, W.Wb0T, H, Bf.g_h0, H, nullptr, N, nullptr, H, H, 0);
-  hipLaunchKernelGGL(hk_b_mul_dsilu, dim3(nblk((long long)N * H)), dim3(256), 0, st, (long long)N * H, D.act, Bf.a0,
+  VSN_HK(hk_b_mul_dsilu), dim3(nblk((long long)N * H)), dim3(256), 0, st, (long long)N * H, D.act, Bf.a0,
                      Bf.g_h0);
   rc |= launch_gemm(st, Bf.g_h0, H, W.Wa0T, H, Bf.g_cat0, 2 * H, nullptr, N, nullptr, 2 * H, H, 0);
   hipLaunchKernelGGL(hk_b_norm_s, dim3(nblk((long long)N * H)), dim3(256), 0, st, N, S, H, Bf.g_cat0, 2 * H, H,

@@ -26,6 +26,38 @@ namespace vsn {
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
     else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
   } while (0)
+// kernels that evaluate activations take a 4th parameter GEN: false = the all-silu network (the reference default;
+// the activation folds to the branch-free silu), true = kinds read from Dims at run time (utils.py:93-116 table)
+#define VSN_DISPATCH3A(V_, S_, W_, G_, FN, ...)                                \
+  do {                                                                         \
+    if ((W_) == 1) {                                                           \
+      if (G_) FN<V_, S_, 1, true> __VA_ARGS__;                                 \
+      else FN<V_, S_, 1, false> __VA_ARGS__;                                   \
+    } else {                                                                   \
+      if (G_) FN<V_, S_, VSN_WPN_SMALL, true> __VA_ARGS__;                     \
+      else FN<V_, S_, VSN_WPN_SMALL, false> __VA_ARGS__;                       \
+    }                                                                          \
+  } while (0)
+#define VSN_DISPATCH_VA(V_, S_, W_, G_, FN, ...)                               \
+  do {                                                                         \
+    if ((S_) == 8) VSN_DISPATCH3A(V_, 8, W_, G_, FN, __VA_ARGS__);             \
+    else if ((S_) == 3) VSN_DISPATCH3A(V_, 3, W_, G_, FN, __VA_ARGS__);        \
+    else return -22;                                                           \
+  } while (0)
+#define VSN_DISPATCH_VSA(H_, S_, W_, G_, FN, ...)                              \
+  do {                                                                         \
+    switch ((H_) / 64) {                                                       \
+      case 1: VSN_DISPATCH_VA(1, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 2: VSN_DISPATCH_VA(2, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 3: VSN_DISPATCH_VA(3, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 4: VSN_DISPATCH_VA(4, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 5: VSN_DISPATCH_VA(5, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 6: VSN_DISPATCH_VA(6, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 7: VSN_DISPATCH_VA(7, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 8: VSN_DISPATCH_VA(8, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      default: return -22;                                                     \
+    }                                                                          \
+  } while (0)
 #define VSN_DISPATCH_V(V_, S_, W_, FN, ...)                              \
   do {                                                                   \
     if ((S_) == 8) VSN_DISPATCH3(V_, 8, W_, FN, __VA_ARGS__);            \
@@ -117,7 +149,7 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // wd = u1.u2 + a1 a2 cc ; df = silu(pf) wd
 // g_pf = g_f wd silu'(pf) ; g_wd = g_f silu(pf)
 // g_wt_i = sum_e g_wd (u2 + a2 cc d) ; g_d += sum_c g_wd (cc (a2 u1 + a1 u2) + 2 a1 a2 d)
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
@@ -159,7 +191,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         float sp, dsp;
-        act_both(D.act, pf[c], sp, dsp);
+        act_both((GEN ? D.act : VSN_ACT_SILU), pf[c], sp, dsp);
         const float wd = dot[c] + a1[c] * a2[c] * cc;
         gpf[c] = gf[c] * wd * dsp;
         gwd[c] = gf[c] * sp;
@@ -192,7 +224,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
 }
 
 // ---- adjoint of the edge update, source side: g_ws_j = sum_{e: src=j} g_wd (u1 + a1 cc d) ----
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_vp) {
@@ -226,7 +258,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
       ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
       ldrow<V>(g_f + (size_t)e * H, lane, gf);
 #pragma unroll
-      for (int c = 0; c < V; ++c) gwd[c] = gf[c] * act_f(D.act, pf[c]);
+      for (int c = 0; c < V; ++c) gwd[c] = gf[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pf[c]);
 #pragma unroll
       for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
 // ---- adjoint of the vector messages, target side -----------------------------------
 // mv_e[s] = vh_j[s] s1 + d_s s2 ; g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_s
 // g_t = [g_s1 silu'(t1) | g_s2 silu'(t2)] ; g_d[s] += sum_c g_vec_i[s] s2
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
     float* __restrict__ g_t, float* __restrict__ g_geo) {
@@ -264,8 +296,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        d1[c] = dact_f(D.act, t1[c]);
-        act_both(D.act, t2[c], s2[c], d2[c]);
+        d1[c] = dact_f((GEN ? D.act : VSN_ACT_SILU), t1[c]);
+        act_both((GEN ? D.act : VSN_ACT_SILU), t2[c], s2[c], d2[c]);
       }
       float gs1[V], gs2[V];
 #pragma unroll
@@ -302,7 +334,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
 }
 
 // ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
       float s1[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, s1);
 #pragma unroll
-      for (int c = 0; c < V; ++c) s1[c] = act_f(D.act, s1[c]);
+      for (int c = 0; c < V; ++c) s1[c] = act_f((GEN ? D.act : VSN_ACT_SILU), s1[c]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         float gv[V];
@@ -343,7 +375,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
 // gm = g_m_e + g_A_i (overwrites g_m) ; recompute sat, a
 // g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a silu'(sat) C ; g_C += sum_h g_a silu(sat)
 // g_pk = g_sat q_i k_j silu'(pk) ; g_pv = gm v_j a silu'(pv) ; g_q_i = sum_e g_sat k_j dk
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
@@ -395,8 +427,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gm[c] += gA[c];
-        act_both(D.act, pk[c], dk[c], ddk[c]);
-        act_both(D.act, pv[c], dv[c], ddv[c]);
+        act_both((GEN ? D.act : VSN_ACT_SILU), pk[c], dk[c], ddk[c]);
+        act_both((GEN ? D.act : VSN_ACT_SILU), pv[c], dv[c], ddv[c]);
         part += q[c] * k[c] * dk[c];
         gpart += gm[c] * v[c] * dv[c];
       }
@@ -404,7 +436,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       const float sat = group_sum(part, lph);
       const float ga = group_sum(gpart, lph);
       float ssat, dssat;
-      act_both(D.attn_act, sat, ssat, dssat);
+      act_both((GEN ? D.attn_act : VSN_ACT_SILU), sat, ssat, dssat);
       const float a = ssat * C;
       const float gsat = ga * dssat * C;
       const bool head_lead = (lane & (lph - 1)) == 0;
@@ -430,7 +462,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
 }
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_m,
     const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
@@ -457,8 +489,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
       const float a = sat_tmp[(size_t)e * 2 * nh + nh + lane / lph];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        g2[0][c] += gsat * q[c] * act_f(D.act, pk[c]);
-        g2[1][c] += gm[c] * act_f(D.act, pv[c]) * a;
+        g2[0][c] += gsat * q[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+        g2[1][c] += gm[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * a;
       }
     }
     node_reduce<V, 2, WPN>(g2, smem, lane, sub);
@@ -798,6 +830,13 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
 }
 
 // ---- launchers -----------------------------------------------------------------------
+#define VSN_LAUNCH_ACT(KN, RK, ...)                                                                     \
+  do {                                                                                                  \
+    const int w__ = pick_wpn(D.N);                                                                      \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KN,                                                            \
+                     <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
+  } while (0)
 #define VSN_LAUNCH(KN, RK, ...)                                                                         \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
@@ -815,27 +854,27 @@ int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, cons
 int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
                            float* g_pe, float* g_vp, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
-  VSN_LAUNCH(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
+  VSN_LAUNCH_ACT(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
+  VSN_LAUNCH_ACT(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
   return 0;
 }
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
                       float* g_t, float* g_vh, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_vecmsg_T, 0, D, g_vec, vh, tpre, g_t, g_geo);
-  if (g_vh) VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
+  VSN_LAUNCH_ACT(k_bwd_vecmsg_T, 0, D, g_vec, vh, tpre, g_t, g_geo);
+  if (g_vh) VSN_LAUNCH_ACT(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
   return 0;
 }
 int launch_bwd_vecmsg_S(hipStream_t st, const Dims& D, const float* g_vec, const float* tpre, float* g_vh) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
+  VSN_LAUNCH_ACT(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
   return 0;
 }
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts);
-  VSN_LAUNCH(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
+  VSN_LAUNCH_ACT(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts);
+  VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
   return 0;
 }
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh,

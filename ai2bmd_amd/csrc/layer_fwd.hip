@@ -24,6 +24,38 @@ namespace vsn {
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
     else FN<V_, S_, VSN_WPN_SMALL> __VA_ARGS__;                          \
   } while (0)
+// kernels that evaluate activations take a 4th parameter GEN: false = the all-silu network (the reference default;
+// the activation folds to the branch-free silu), true = kinds read from Dims at run time (utils.py:93-116 table)
+#define VSN_DISPATCH3A(V_, S_, W_, G_, FN, ...)                                \
+  do {                                                                         \
+    if ((W_) == 1) {                                                           \
+      if (G_) FN<V_, S_, 1, true> __VA_ARGS__;                                 \
+      else FN<V_, S_, 1, false> __VA_ARGS__;                                   \
+    } else {                                                                   \
+      if (G_) FN<V_, S_, VSN_WPN_SMALL, true> __VA_ARGS__;                     \
+      else FN<V_, S_, VSN_WPN_SMALL, false> __VA_ARGS__;                       \
+    }                                                                          \
+  } while (0)
+#define VSN_DISPATCH_VA(V_, S_, W_, G_, FN, ...)                               \
+  do {                                                                         \
+    if ((S_) == 8) VSN_DISPATCH3A(V_, 8, W_, G_, FN, __VA_ARGS__);             \
+    else if ((S_) == 3) VSN_DISPATCH3A(V_, 3, W_, G_, FN, __VA_ARGS__);        \
+    else return -22;                                                           \
+  } while (0)
+#define VSN_DISPATCH_VSA(H_, S_, W_, G_, FN, ...)                              \
+  do {                                                                         \
+    switch ((H_) / 64) {                                                       \
+      case 1: VSN_DISPATCH_VA(1, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 2: VSN_DISPATCH_VA(2, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 3: VSN_DISPATCH_VA(3, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 4: VSN_DISPATCH_VA(4, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 5: VSN_DISPATCH_VA(5, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 6: VSN_DISPATCH_VA(6, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 7: VSN_DISPATCH_VA(7, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      case 8: VSN_DISPATCH_VA(8, S_, W_, G_, FN, __VA_ARGS__); break;          \
+      default: return -22;                                                     \
+    }                                                                          \
+  } while (0)
 #define VSN_DISPATCH_V(V_, S_, W_, FN, ...)                              \
   do {                                                                   \
     if ((S_) == 8) VSN_DISPATCH3(V_, 8, W_, FN, __VA_ARGS__);            \
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(256) void k_node_norm(Dims D, const float* __restri
 
 // ---- attention + scalar message + its aggregation (visnet_block.py:276-283,305) --
 // a_h = silu(sum_c q_i k_j dk) * C ; m_e = v_j * dv * a ; A_i = sum_e m_e
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __restrict__ qkv,
                                                const float* __restrict__ pe, float* __restrict__ m,
                                                float* __restrict__ A, float* __restrict__ smem, int bid, int nblk) {
@@ -201,12 +233,12 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
       float part = 0.f;
 #pragma unroll
-      for (int c = 0; c < V; ++c) part += q[c] * k[c] * act_f(D.act, pk[c]);
+      for (int c = 0; c < V; ++c) part += q[c] * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
       const float sat = group_sum(part, lph);
-      const float a = act_f(D.attn_act, sat) * C;
+      const float a = act_f((GEN ? D.attn_act : VSN_ACT_SILU), sat) * C;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        mv[c] = v[c] * act_f(D.act, pv[c]) * a;
+        mv[c] = v[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * a;
         acc[0][c] += mv[c];
       }
       strow<V>(m + (size_t)e * H, lane, mv);
@@ -215,13 +247,13 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
     if (sub == 0) strow<V>(A + (size_t)i * H, lane, acc[0]);
   }
 }
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D, const float* __restrict__ qkv,
                                                                          const float* __restrict__ pe,
                                                                          float* __restrict__ m,
                                                                          float* __restrict__ A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  edge_attn_body<V, S, WPN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, (int)gridDim.x);
+  edge_attn_body<V, S, WPN, GEN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // fused LayerNorm of the NEXT layer / read-out on one node row held by a wave (same arithmetic as k_node_norm)
@@ -255,7 +287,7 @@ __device__ __forceinline__ void node_layernorm_store(const NextNorm& nn, int i, 
 // ---- vector messages, their aggregation and the node update ---------------------
 // V_i[s] = sum_e vh_j[s]*s1_e + d_e[s]*s2_e ; dx = (sum_s vec1 vec2) o2 + o3 ;
 // dvec = vec3 o1 + V ; x += dx ; vec += dvec    (visnet_block.py:284-288,271-274,129-137)
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims D, const float* __restrict__ tpre,
                                                                            const float* __restrict__ vh,
                                                                            const float* __restrict__ vp,
@@ -279,8 +311,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, s2);
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        s1[c] = act_f(D.act, s1[c]);
-        s2[c] = act_f(D.act, s2[c]);
+        s1[c] = act_f((GEN ? D.act : VSN_ACT_SILU), s1[c]);
+        s2[c] = act_f((GEN ? D.act : VSN_ACT_SILU), s2[c]);
       }
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -389,7 +421,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
 
 // ---- edge update (visnet_block.py:290-295): f_e += silu(pf_e) * <rej(wt_i,d), rej(ws_j,d)> ---
 // <w1,w2> = u1.u2 + (u1.d)(u2.d)(|d|^2 - 2)   (expanded double rejection)
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __device__ __forceinline__ void edge_update_body(const Dims& D, const float* __restrict__ vp,
                                                  const float* __restrict__ pe, float* __restrict__ f, int bid,
                                                  int nblk) {
@@ -423,21 +455,21 @@ __device__ __forceinline__ void edge_update_body(const Dims& D, const float* __r
       ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
       ldrow<V>(f + (size_t)e * H, lane, fv);
 #pragma unroll
-      for (int c = 0; c < V; ++c) fv[c] += act_f(D.act, pf[c]) * (dot[c] + a1[c] * a2[c] * cc);
+      for (int c = 0; c < V; ++c) fv[c] += act_f((GEN ? D.act : VSN_ACT_SILU), pf[c]) * (dot[c] + a1[c] * a2[c] * cc);
       strow<V>(f + (size_t)e * H, lane, fv);
     }
   }
 }
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims D, const float* __restrict__ vp,
                                                                            const float* __restrict__ pe,
                                                                            float* __restrict__ f) {
-  edge_update_body<V, S, WPN>(D, vp, pe, f, (int)blockIdx.x, (int)gridDim.x);
+  edge_update_body<V, S, WPN, GEN>(D, vp, pe, f, (int)blockIdx.x, (int)gridDim.x);
 }
 // Horizontal fusion of the two independent edge walks of a layer (both consume the edge linears `pe`):
 // blocks [0, G) do the attention, blocks [G, 2G) the edge update.  On a single protein both are latency-bound,
 // so one launch runs them side by side without the ~15 us event latency a second stream would cost.
-template <int V, int S, int WPN>
+template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(Dims D, const float* __restrict__ qkv,
                                                                                 const float* __restrict__ pe,
                                                                                 float* __restrict__ m,
@@ -446,11 +478,18 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(
                                                                                 float* __restrict__ f) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int G = (int)gridDim.x >> 1;
-  if ((int)blockIdx.x < G) edge_attn_body<V, S, WPN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, G);
-  else edge_update_body<V, S, WPN>(D, vp, pe, f, (int)blockIdx.x - G, G);
+  if ((int)blockIdx.x < G) edge_attn_body<V, S, WPN, GEN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, G);
+  else edge_update_body<V, S, WPN, GEN>(D, vp, pe, f, (int)blockIdx.x - G, G);
 }
 
 // ---- launchers -------------------------------------------------------------------
+#define VSN_LAUNCH_ACT(KN, RK, ...)                                                                     \
+  do {                                                                                                  \
+    const int w__ = pick_wpn(D.N);                                                                      \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KN,                                                            \
+                     <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
+  } while (0)
 #define VSN_LAUNCH(KN, RK, ...)                                                                         \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
@@ -481,27 +520,28 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
 }
 int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_edge_attn, 1, D, qkv, pe, m, A);
+  VSN_LAUNCH_ACT(k_edge_attn, 1, D, qkv, pe, m, A);
   return 0;
 }
 int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A,
                             const float* vp, float* f) {
   if (D.N <= 0) return 0;
   const int w__ = pick_wpn(D.N);
-  VSN_DISPATCH_VS(D.H, D.S, w__, k_edge_attn_update,
-                  <<<2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st>>>(D, qkv, pe, m, A,
-                                                                                                   vp, f));
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  VSN_DISPATCH_VSA(D.H, D.S, w__, g__, k_edge_attn_update,
+                   <<<2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st>>>(D, qkv, pe, m, A,
+                                                                                                    vp, f));
   return 0;
 }
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
                        const float* o, float* x, float* vec, const NextNorm& nn) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_node_update, D.S, D, tpre, vh, vp, o, x, vec, nn);
+  VSN_LAUNCH_ACT(k_node_update, D.S, D, tpre, vh, vp, o, x, vec, nn);
   return 0;
 }
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_edge_update, 0, D, vp, pe, f);
+  VSN_LAUNCH_ACT(k_edge_update, 0, D, vp, pe, f);
   return 0;
 }
 

@@ -18,16 +18,21 @@ from oracle.weights import default_hparams, make_state_dict
 pytestmark = pytest.mark.gpu
 
 
-def check(E, F, E64, F64):
+def check(E, F, E64, F64, ref32=None):
+    """ref32 = (E_ref32, F_ref32): where the reference's OWN fp32 evaluation is further from the fp64 truth than the
+    fixed tolerance (ill-conditioned weight draws), 4x its error is the bar instead."""
     E, F = np.asarray(E, np.float64), np.asarray(F, np.float64)
     assert E.shape == E64.shape and F.shape == F64.shape
     assert np.isfinite(E).all() and np.isfinite(F).all()
+    e_floor = 4 * np.abs(ref32[0] - E64).max() if ref32 is not None else 0.0
+    mae_floor = 4 * np.abs(ref32[1] - F64).mean() if ref32 is not None else 0.0
+    max_floor = 4 * np.abs(ref32[1] - F64).max() if ref32 is not None else 0.0
     de = np.abs(E - E64)
-    assert (de <= 1e-5 * np.maximum(1.0, np.abs(E64))).all(), f"dE max {de.max():.3e}"
+    assert (de <= np.maximum(1e-5 * np.maximum(1.0, np.abs(E64)), e_floor)).all(), f"dE max {de.max():.3e}"
     mae = np.abs(F - F64).mean()
-    assert mae <= 1e-5 * max(1.0, np.abs(F64).mean()), f"force MAE {mae:.3e}"
+    assert mae <= max(1e-5 * max(1.0, np.abs(F64).mean()), mae_floor), f"force MAE {mae:.3e}"
     mx = np.abs(F - F64).max()
-    assert mx <= 1e-4 * max(1.0, np.abs(F64).max()), f"force max err {mx:.3e}"
+    assert mx <= max(1e-4 * max(1.0, np.abs(F64).max()), max_floor), f"force max err {mx:.3e}"
 
 
 def model_for(hp, seed):
@@ -48,7 +53,7 @@ def test_golden_reference_vectors(lib_built, name):
     m = model_for(g["hparams"], g["weight_seed"])
     e, f = m.dl_potential_loader(frag(g["z"], g["pos"], g["start"], g["end"]))
     assert e.dtype == np.float32 and f.dtype == np.float32 and e.shape[1] == 1 and f.shape[1] == 3
-    check(e, f, g["E_ref64"], g["F_ref64"])
+    check(e, f, g["E_ref64"], g["F_ref64"], ref32=(g["E_ref32"], g["F_ref32"]))
     # and no worse than 4x the reference's own fp32 error (floor 2e-6 abs)
     ref_err = max(np.abs(g["F_ref32"] - g["F_ref64"]).max(), 2e-6)
     assert np.abs(f - g["F_ref64"]).max() <= 4 * ref_err + 1e-6 * np.abs(g["F_ref64"]).max()
@@ -322,3 +327,53 @@ def test_visnet_model_takes_a_loaded_model_like_the_reference(lib_built, tmp_pat
     m = ViSNetModel(load_model(path), device="cuda:0")
     e, f = m.dl_potential_loader(frag(g["z"], g["pos"], g["start"], g["end"]))
     check(e, f, g["E_ref64"], g["F_ref64"])
+
+
+def _big_cluster(n, cutoff, seed):
+    """jittered cubic lattice (2.1 A spacing), nudged until no pair distance sits within 5e-5 A of the cutoff, so
+    that the fp32 d^2 < rc^2 test of the kernel and the fp64 one of the oracle select the same edges"""
+    rng = np.random.default_rng(seed)
+    m = int(np.ceil(n ** (1 / 3)))
+    grid = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n]
+    pos = ((grid - grid.mean(0)) * 2.1 + rng.normal(0, 0.25, (n, 3))).astype(np.float32)
+    for _ in range(50):
+        p = pos.astype(np.float64)
+        d = np.sqrt(((p[:, None] - p[None]) ** 2).sum(-1))
+        bad = np.argwhere(np.abs(d - cutoff) < 5e-5)
+        if len(bad) == 0:
+            return pos
+        for i in set(bad[:, 0].tolist()):
+            pos[i] += rng.normal(0, 0.01, 3).astype(np.float32)
+    raise RuntimeError("could not separate pair distances from the cutoff")
+
+
+@pytest.mark.parametrize("sizes", [[2000], [700, 12, 0, 1300]])
+def test_whole_molecule_graph_is_node_parallel_and_matches_the_oracle(lib_built, sizes):
+    """`--mode visnet` (visnet_calculator.py:139-155): one fragment = the whole system.  Fragments larger than a
+    wavefront take the node-parallel graph passes (graph.hip k_graph_*_big); edge set, order-dependent truncation
+    and E/F against the oracle at N = 2000, with and without neighbour truncation."""
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    rng = np.random.default_rng(8)
+    n = sum(sizes)
+    end = np.cumsum(sizes)
+    start = end - np.asarray(sizes)
+    pos = np.zeros((n, 3), np.float32)
+    for k, (a, b) in enumerate(zip(start, end)):
+        if b > a:
+            pos[a:b] = _big_cluster(b - a, 5.0, 100 + k) + np.float32(40.0 * k)
+    z = rng.choice([1, 6, 7, 8], size=n).astype(np.int64)
+    for mnb in (160, 32):   # 160: nothing truncated (~60 neighbours); 32: every target truncated, lowest indices kept
+        hp = default_hparams(embedding_dimension=64, num_layers=2, max_num_neighbors=mnb)
+        sd = make_state_dict(hp, seed=12)
+        E64, F64, c = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+        m = ViSNetModel(hp, sd, device="cuda:0")
+        e, f = m.dl_potential_loader(frag(z, pos, start, end))
+        assert m.engine.last_num_edges() == len(c["graph"]["src"])
+        src = m.engine.debug_read("src", dtype=np.int32)
+        rowptr = m.engine.debug_read("rowptr", dtype=np.int32)
+        assert np.array_equal(src, c["graph"]["src"]) and np.array_equal(rowptr, c["graph"]["rowptr"])
+        perm = m.engine.debug_read("perm", dtype=np.int32)
+        colptr = m.engine.debug_read("colptr", dtype=np.int32)
+        assert np.array_equal(perm, c["graph"]["perm"]) and np.array_equal(colptr, c["graph"]["colptr"])
+        check(e, f, E64, F64)

@@ -198,16 +198,20 @@ int main() {
              hipLaunchKernelGGL((vsn::k_gemm<64, 64, 2, 2, true>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc,
                                 bias, s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);
            }));
+#define RUN_PROD(NAME, ...)                                                                                       \
+  hipMemset(C, 0, nc * 4);                                                                                        \
+  report(NAME, time_us([&] {                                                                                      \
+           hipLaunchKernelGGL((vsn::k_gemm<__VA_ARGS__>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc, bias, \
+                              s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                                            \
+         }));
+    RUN_PROD("64x64 db pf2", 64, 64, 2, 2, true, 0, 32, 2)
+    RUN_PROD("64x64 db bk16 pf2", 64, 64, 2, 2, true, 0, 16, 2)
 #define RUN_DIRECT(PD, X)                                                                                        \
   hipMemset(C, 0, nc * 4);                                                                                       \
   report("direct pd" #PD " xcd" #X, time_us([&] {                                                                 \
            hipLaunchKernelGGL((k_direct<PD, X>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc, bias, s.M, \
                               s.Nc, s.K);                                                                         \
          }));
-    RUN_DIRECT(2, true)
-    RUN_DIRECT(3, true)
-    RUN_DIRECT(4, true)
-    RUN_DIRECT(3, false)
     hipFree(A);
     hipFree(B);
     hipFree(C);
