@@ -103,6 +103,7 @@ struct vsn_ctx {
   // more than the 11-16 us forward edge update it hides, so only the reverse pass (50-60 us of side work per layer) forks.
   int overlap = 2;
   bool fuse_fwd = true, fuse_bwd_opt = true;
+  bool fuse_head = true;  // fused node-local head kernel (head_fused.hip) on single-protein sizes
   bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
@@ -117,7 +118,8 @@ struct vsn_ctx {
   size_t pin_cap = 0;
   hipEvent_t ev_upload = nullptr;  // recorded after the last upload: the staging buffer is free once it has fired
   int n_atomref = 0;           // rows of the Atomref table (prior_args.max_z; independent of hparams.max_z)
-  int* status = nullptr;       // device status flag of the last chunk
+  int* status = nullptr;       // device status word: epoch of the last chunk that saw an invalid atomic number
+  int epoch = 0;               // chunk counter (the status word is compared with it instead of being cleared)
 };
 
 static int fail(vsn_ctx* c, int code, const std::string& msg) {
@@ -211,6 +213,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->fuse_fwd = value != 0;
   } else if (k == "fuse_bwd") {
     c->fuse_bwd_opt = value != 0;
+  } else if (k == "fuse_head") {
+    c->fuse_head = value != 0;
   } else if (k == "split_rev") {
     c->split_rev = value != 0;
   } else if (k == "overlap") {
@@ -578,7 +582,7 @@ static void carve(vsn_ctx* c, int N, int E, int Bn) {
   c->g_pp = a.take<float>(e * 2 * H);
   c->g_n = a.take<float>(n * H);
   c->g_rbf = a.take<float>(e * Rp);
-  c->g_geo = a.take<float>(e * VSN_GEO_W + 64);  // + the chunk's status word, cleared by the same memset
+  c->g_geo = a.take<float>(e * VSN_GEO_W);
   c->g_ev = a.take<float>(e * 4);
   // split-K partials: up to 8 slices of the widest narrow output ([E,H] or [S*N,H])
   c->splitk_elems = 8 * std::max(e, n * S) * H;
@@ -618,6 +622,8 @@ static int ensure_ws(vsn_ctx* c, int N, int E, int Bn) {
   // layer 0 sees vec == 0 (visnet_block.py:119-121): its vector projections are identically zero and are
   // never computed; the buffer is cleared once per allocation.
   HIPCHK(c, hipMemset(c->lb[0].vp, 0, (size_t)nN * c->S * 5 * c->H * sizeof(float)));
+  HIPCHK(c, hipMemset(c->ecount, 0, 64 * sizeof(int)));
+  c->epoch = 0;
   return 0;
 }
 
@@ -696,8 +702,13 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   g.tgt = c->tgt;
   g.perm = c->perm;
   g.ecount = c->ecount;
-  c->status = reinterpret_cast<int*>(c->g_geo + (size_t)Emax * VSN_GEO_W);
+  c->status = c->ecount + 1;  // zeroed when the workspace is carved; holds the epoch of the last chunk with a bad z
+  c->epoch = c->epoch >= 0x7ffffff0 ? 1 : c->epoch + 1;
   g.status = c->status;
+  g.epoch = c->epoch;
+  g.g_geo = c->g_geo;
+  c->hw.epoch = c->epoch;
+  c->hw.fuse = (c->fuse_head && !c->debug) ? 1 : 0;
   g.z_limit = c->hw.atomref ? std::min(c->Z, c->n_atomref) : c->Z;
   c->hw.status = c->status;
   g.geo = c->geo;
@@ -731,8 +742,8 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (r__) return fail(c, r__, std::string("launch failed: ") + #call); \
   } while (0)
 
-  HIPCHK(c, hipMemsetAsync(c->g_geo, 0, ((size_t)Emax * VSN_GEO_W + 16) * sizeof(float), st));  // incl. status
-  HIPCHK(c, hipMemsetAsync(c->g_f, 0, (size_t)Emax * H * sizeof(float), st));
+  // no memsets per evaluation: k_edge_geom clears the g_geo row of every live edge, the first writer of g_f (the
+  // last layer's dX group) does not accumulate, and the status word is an epoch stamp
   RC(launch_graph(st, g));
   // ---- embeddings ----
   RC(launch_gemm(st, c->rbf, Rp, c->Wrbf, Rp, c->pp, 2 * H, c->brbf, Emax, EP, 2 * H, Rp, 0));
@@ -888,7 +899,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       GemmDesc gd[3];
       int ng = 0;
       gd[ng++] = gemm_desc(c->g_pe, 3 * H, w.We3T, 3 * H, c->g_f, H, nullptr, Emax, EP, H,
-                           (last || l0) ? 2 * H : 3 * H, 1);
+                           (last || l0) ? 2 * H : 3 * H, last ? 0 : 1);  // the last layer is g_f's first writer
       if (!l0)
         gd[ng++] = gemm_desc(c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
                              last ? 3 * H : 5 * H, 1);
@@ -1043,7 +1054,7 @@ extern "C" int vsn_last_status(vsn_handle c) {
   hipDeviceSynchronize();
   int v = 0;
   if (hipMemcpy(&v, c->status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -5;
-  return v;
+  return v == c->epoch ? 1 : 0;
 }
 
 extern "C" int64_t vsn_debug_read(vsn_handle c, const char* name, int layer, void* host_out, int64_t max_elems) {

@@ -28,7 +28,8 @@ __device__ __forceinline__ float dist2(const float* __restrict__ pos, int a, int
 // status flag; the final kernels then poison energies and forces with NaN and vsn_last_status() reports it.
 __global__ void k_graph_count(const float* __restrict__ pos, const long long* __restrict__ z64,
                               const int* __restrict__ fstart, const int* __restrict__ fend, int* __restrict__ deg,
-                              int* __restrict__ zi, float rc2, int max_nb, int z_limit, int* __restrict__ status) {
+                              int* __restrict__ zi, float rc2, int max_nb, int z_limit, int* __restrict__ status,
+                              int epoch) {
   const int b = blockIdx.x;
   const int s = fstart[b], n = fend[b] - s;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -38,7 +39,7 @@ __global__ void k_graph_count(const float* __restrict__ pos, const long long* __
     deg[s + i] = cnt;
     const long long zv = z64[s + i];
     const bool bad = zv < 0 || zv >= (long long)z_limit;
-    if (bad) atomicOr(status, 1);
+    if (bad) atomicMax(status, epoch);
     zi[s + i] = bad ? 0 : (int)zv;
   }
 }
@@ -154,7 +155,7 @@ __device__ __forceinline__ int frag_of(const int* __restrict__ fend, int B, int 
 __global__ void k_graph_count_big(const float* __restrict__ pos, const long long* __restrict__ z64,
                                   const int* __restrict__ fstart, const int* __restrict__ fend, int B, int N,
                                   int* __restrict__ deg, int* __restrict__ zi, float rc2, int max_nb, int z_limit,
-                                  int* __restrict__ status) {
+                                  int* __restrict__ status, int epoch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int b = frag_of(fend, B, i);
@@ -165,7 +166,7 @@ __global__ void k_graph_count_big(const float* __restrict__ pos, const long long
   deg[i] = cnt;
   const long long zv = z64[i];
   const bool bad = zv < 0 || zv >= (long long)z_limit;
-  if (bad) atomicOr(status, 1);
+  if (bad) atomicMax(status, epoch);
   zi[i] = bad ? 0 : (int)zv;
 }
 
@@ -224,12 +225,13 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
                             const int* __restrict__ ecount, const float* __restrict__ means,
                             const float* __restrict__ betas, int rbf_type, int R, int Rp, float rc, float alpha, int S,
                             float* __restrict__ geo /*[E,8]: r,C,dC,ux,uy,uz,rinv,pad*/, float* __restrict__ d,
-                            float* __restrict__ rbf, float* __restrict__ drbf) {
+                            float* __restrict__ rbf, float* __restrict__ drbf, float* __restrict__ g_geo) {
   const int E = *ecount;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long e = gid / Rp;
   const int k = (int)(gid % Rp);
   if (e >= E) return;
+  if (k < 24) g_geo[e * 24 + k] = 0.f;  // the reverse pass accumulates dE/dd, dE/dC per edge here (Rp >= 32 > 24)
   const int j = src[e], i = tgt[e];
   float ex = pos[3 * j + 0] - pos[3 * i + 0];
   float ey = pos[3 * j + 1] - pos[3 * i + 1];
@@ -329,7 +331,7 @@ __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restri
 // 16 lanes per atom stride over its ~17 in- and ~17 out-edges (one thread per atom walked 34 dependent loads).
 __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int* __restrict__ colptr,
                                const int* __restrict__ perm, const float* __restrict__ g_ev,
-                               float* __restrict__ f_out, const int* __restrict__ status) {
+                               float* __restrict__ f_out, const int* __restrict__ status, int epoch) {
   const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
   const bool live = i < N;
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -349,7 +351,7 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
   fx = group_sum(fx, 16);
   fy = group_sum(fy, 16);
   fz = group_sum(fz, 16);
-  if (*status) fx = fy = fz = __builtin_nanf("");  // invalid input (atomic number out of range): fail loudly
+  if (*status == epoch) fx = fy = fz = __builtin_nanf("");  // invalid input (atomic number out of range): fail loudly
   if (live && l == 0) {
     f_out[3 * (size_t)i + 0] = fx;
     f_out[3 * (size_t)i + 1] = fy;
@@ -361,7 +363,7 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.B <= 0 || a.N <= 0) return 0;
   if (a.max_frag <= 64) {
     hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
-                       a.max_nb, a.z_limit, a.status);
+                       a.max_nb, a.z_limit, a.status, a.epoch);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
     hipLaunchKernelGGL(k_graph_fill_small, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr, a.src,
                        a.tgt, a.colptr, a.perm, a.rc2, a.max_nb);
@@ -369,7 +371,7 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
     // a fragment larger than a wavefront somewhere in the batch: node-parallel passes (any mix of sizes)
     const dim3 grid((a.N + 255) / 256), blk(256);
     hipLaunchKernelGGL(k_graph_count_big, grid, blk, 0, st, a.pos, a.z64, a.fstart, a.fend, a.B, a.N, a.deg, a.zi,
-                       a.rc2, a.max_nb, a.z_limit, a.status);
+                       a.rc2, a.max_nb, a.z_limit, a.status, a.epoch);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
     hipLaunchKernelGGL(k_graph_fill_big, grid, blk, 0, st, a.pos, a.fstart, a.fend, a.B, a.N, a.rowptr, a.src, a.tgt,
                        a.rc2, a.max_nb);
@@ -384,7 +386,7 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   int blocks = (int)((tot + 255) / 256);
   if (blocks > 0)
     hipLaunchKernelGGL(k_edge_geom, dim3(blocks), dim3(256), 0, st, a.pos, a.src, a.tgt, a.ecount, a.means, a.betas,
-                       a.rbf_type, a.R, a.Rp, a.rc, a.alpha, a.S, a.geo, a.d, a.rbf, a.drbf);
+                       a.rbf_type, a.R, a.Rp, a.rc, a.alpha, a.S, a.geo, a.d, a.rbf, a.drbf, a.g_geo);
   return 0;
 }
 
@@ -396,7 +398,7 @@ int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, cons
     hipLaunchKernelGGL(k_bwd_geom, dim3(blocks), dim3(256), 0, st, a.ecount, a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S,
                        g_ev);
   hipLaunchKernelGGL(k_force_gather, dim3((a.N + 15) / 16), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
-                     g_ev, f_out, a.status);
+                     g_ev, f_out, a.status, a.epoch);
   return 0;
 }
 

@@ -43,12 +43,18 @@ __global__ void hk_mid(int N, int S, int H, int act, const float* __restrict__ u
 template <bool GEN>
 __global__ void hk_final(int N, int h2, int act, const float* __restrict__ a1b, const float* __restrict__ wb1, float bb1,
                          float stdv, const float* __restrict__ atomref, const int* __restrict__ zi,
-                         float* __restrict__ y) {
+                         float* __restrict__ y, float* __restrict__ g_a1) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (i >= N) return;
   float acc = 0.f;
-  for (int c = lane; c < h2; c += 64) acc += act_f(GEN ? act : VSN_ACT_SILU, a1b[(size_t)i * h2 + c]) * wb1[c];
+  for (int c = lane; c < h2; c += 64) {
+    float av, dav;
+    act_both(GEN ? act : VSN_ACT_SILU, a1b[(size_t)i * h2 + c], av, dav);
+    acc += av * wb1[c];
+    // first step of the reverse pass rides along (dE/dy = 1): g_a1 = std * wb1 * act'(a1b)
+    g_a1[(size_t)i * h2 + c] = stdv * wb1[c] * dav;
+  }
   acc = wave_sum(acc);
   if (lane == 0) {
     float v = (acc + bb1) * stdv;
@@ -59,24 +65,15 @@ __global__ void hk_final(int N, int h2, int act, const float* __restrict__ a1b, 
 
 __global__ void hk_energy(int B, const int* __restrict__ fstart, const int* __restrict__ fend,
                           const float* __restrict__ y, float mean, float* __restrict__ e_out,
-                          const int* __restrict__ status) {
+                          const int* __restrict__ status, int epoch) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float acc = 0.f;
   for (int i = fstart[b]; i < fend[b]; ++i) acc += y[i];
-  e_out[b] = (status && *status) ? __builtin_nanf("") : acc + mean;
+  e_out[b] = (status && *status == epoch) ? __builtin_nanf("") : acc + mean;
 }
 
 // ---- reverse ----
-template <bool GEN>
-__global__ void hk_b_a1(int N, int h2, int act, const float* __restrict__ a1b, const float* __restrict__ wb1, float stdv,
-                        float* __restrict__ g_a1) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long long)N * h2) return;
-  const int c = (int)(gid % h2);
-  g_a1[gid] = stdv * wb1[c] * dact_f(GEN ? act : VSN_ACT_SILU, a1b[gid]);
-}
-
 // g_p[s] = g_v * p[s] / v   (adjoint of the 2-norm over s; 0 where v == 0 like torch.norm)
 __global__ void hk_b_norm_s(int N, int S, int C, const float* __restrict__ g_cat, int ldg, int goff,
                             const float* __restrict__ cat, int ldc, int coff, const float* __restrict__ p, int ldp,
@@ -126,11 +123,18 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
   const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
   if (N <= 0) {
     if (B > 0) hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
-                                  W.status);
+                                  W.status, W.epoch);
     return 0;
   }
   int rc = 0;
   rc |= launch_gemm(st, vo, H, W.Wpv0, H, Bf.pv0, ldp, nullptr, N * S, nullptr, ldp, H, 0);
+  if (W.fuse && head_fused_supported(D)) {
+    // single-protein sizes: the node-local rest of the head, forward and reverse, is one launch
+    rc |= launch_head_fused(st, D, W, Bf);
+    hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
+                                  W.status, W.epoch);
+    return rc;
+  }
   hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * H)), dim3(256), 0, st, N, S, H, Bf.pv0, ldp, Bf.cat0,
                      2 * H, H);
   rc |= launch_gemm(st, Bf.cat0, 2 * H, W.Wa0, 2 * H, Bf.a0, H, W.ba0, N, nullptr, H, 2 * H, 0);
@@ -142,9 +146,9 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
                      h2);
   rc |= launch_gemm(st, Bf.cat1, H, W.Wa1, H, Bf.a1b, h2, W.ba1, N, nullptr, h2, H, 0);
   VSN_HK(hk_final), dim3((N + 3) / 4), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.bb1, W.stdv, W.atomref,
-                     D.zi, Bf.y);
+                     D.zi, Bf.y, Bf.g_a1);
   hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
-                                  W.status);
+                                  W.status, W.epoch);
   return rc;
 }
 
@@ -153,8 +157,8 @@ int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const He
   const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
   if (N <= 0) return 0;
   int rc = 0;
-  VSN_HK(hk_b_a1), dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, h2, D.act, Bf.a1b, W.wb1, W.stdv,
-                     Bf.g_a1);
+  if (W.fuse && head_fused_supported(D))  // everything up to g_pv0 was done by the fused forward launch
+    return launch_gemm(st, Bf.g_pv0, ldp, W.Wpv0T, ldp, g_vo, H, nullptr, N * S, nullptr, H, ldp, 0);
   rc |= launch_gemm(st, Bf.g_a1, h2, W.Wa1T, h2, Bf.g_cat1, H, nullptr, N, nullptr, H, h2, 0);
   hipLaunchKernelGGL(hk_b_norm_s, dim3(nblk((long long)N * h2)), dim3(256), 0, st, N, S, h2, Bf.g_cat1, H, h2,
                      Bf.cat1, H, h2, Bf.p1, h2, Bf.g_p1, h2);

@@ -28,7 +28,9 @@ struct GraphArgs {
   int* perm;
   int* ecount;
   int z_limit;   // valid atomic numbers: 0 <= z < z_limit (embedding rows, atomref rows)
-  int* status;   // device flag of the chunk (bit 0: atomic number out of range); cleared by the engine
+  int* status;   // device word: epoch of the last chunk that saw an atomic number out of range (never cleared)
+  int epoch;     // this chunk's epoch: *status == epoch <=> this chunk is invalid
+  float* g_geo;  // [E,24] reverse-pass accumulators, cleared per live edge by k_edge_geom
   float* geo;   // [E,8]  r, C, dC, ux, uy, uz, 1/r, 0
   float* d;     // [E,8]  spherical harmonics (first S used)
   float* rbf;   // [E,Rp]
@@ -179,7 +181,9 @@ struct HeadW {
   const float* wb1;  // [h2] row 0 of update_net.2 of block 1
   float bb1, mean, stdv;
   const float* atomref;  // [Z] or null
-  const int* status;     // chunk status flag (see GraphArgs): non-zero -> energies are NaN
+  const int* status;     // chunk status word and epoch (see GraphArgs): *status == epoch -> energies are NaN
+  int epoch;
+  int fuse;              // 1: single-protein sizes take the fused head kernel (head_fused.hip) when it fits in LDS
 };
 struct HeadBuf {
   float *cat0, *pv0, *a0, *u0, *vec1o, *cat1, *p1, *a1b, *y;        // forward
@@ -190,6 +194,10 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
                         const int* fstart, const int* fend, int B, float* e_out);
 // leaves dE/d out_norm(x) in Bf.g_cat0[:, :H] (row stride 2H), dE/d vec_out_norm(vec) in g_vo
 int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, float* g_vo);
+
+// the node-local middle of the head (forward AND reverse) in one launch; see head_fused.hip
+bool head_fused_supported(const Dims& D);
+int launch_head_fused(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf);
 
 int launch_fill(hipStream_t st, float* p, size_t n, float v);
 // VecLayerNorm rms (1) / max_min (2): vh = norm(vec), also saves vec into vin for the adjoint

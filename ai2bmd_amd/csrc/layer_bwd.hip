@@ -389,7 +389,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], gA[V], gq[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
-    if (ap.n > 0) {  // dE/dA left as K-slices by the GEMM: sum them here, fixed order
+    if (ap.n == 3) {  // dE/dA left as 3 K-slices by the GEMM: all loads first, then the sum in a fixed order
+      float t1[V], t2[V];
+      ldrow<V>(ap.p + (size_t)i * H, lane, gA);
+      ldrow<V>(ap.p + ap.stride + (size_t)i * H, lane, t1);
+      ldrow<V>(ap.p + 2 * ap.stride + (size_t)i * H, lane, t2);
+#pragma unroll
+      for (int c = 0; c < V; ++c) gA[c] = (gA[c] + t1[c]) + t2[c];
+    } else if (ap.n > 0) {
       ldrow<V>(ap.p + (size_t)i * H, lane, gA);
       for (int k = 1; k < ap.n; ++k) {
         float t[V];
@@ -411,7 +418,13 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
-      if (mp.n > 0) {
+      if (mp.n == 2) {  // the common split: both slices fetched together with the other operands of the edge
+        float t[V];
+        ldrow<V>(mp.p + (size_t)e * H, lane, gm);
+        ldrow<V>(mp.p + mp.stride + (size_t)e * H, lane, t);
+#pragma unroll
+        for (int c = 0; c < V; ++c) gm[c] += t[c];
+      } else if (mp.n > 0) {
         ldrow<V>(mp.p + (size_t)e * H, lane, gm);
         for (int k = 1; k < mp.n; ++k) {
           float t[V];
