@@ -269,3 +269,28 @@ def test_reference_bonded_calculator_drives_our_seam_unchanged(lib_built):
     E_h, F_h = combine_host(plan, E_all.reshape(-1, 1), F_all)
     np.testing.assert_allclose(F_m, F_h, rtol=0, atol=2e-5)
     assert abs(float(E_m) - E_h) < 2e-4 * max(1.0, abs(E_h))
+
+
+def test_hparams_are_recovered_from_a_reference_module():
+    """`ViSNetModel(model, device)` accepts a torch module built by the reference's own create_model: the
+    hyper-parameters are read off the attributes the reference's ViSNetBlock keeps (visnet_block.py:40-55) and the
+    module's state_dict carries the same keys our engine loads."""
+    from ai2bmd_amd.visnet_calculator import hparams_of_module
+    from oracle.ref_import import import_reference_create_model
+
+    create_model = import_reference_create_model()
+    for over in (dict(embedding_dimension=64, num_layers=2),
+                 dict(embedding_dimension=128, num_layers=1, lmax=1, rbf_type="gauss", num_rbf=20, activation="ssp",
+                      attn_activation="tanh", vecnorm_type="rms", num_heads=4, cutoff=4.5, max_num_neighbors=20)):
+        hp = default_hparams(**over)
+        model = create_model(hp)
+        got = hparams_of_module(model)
+        for k in ("embedding_dimension", "num_layers", "num_rbf", "num_heads", "lmax", "max_z", "cutoff",
+                  "max_num_neighbors", "vecnorm_type", "rbf_type", "prior_model"):
+            assert got[k] == hp[k], (k, got[k], hp[k])
+        same = {"silu": ("silu", "swish"), "swish": ("silu", "swish")}
+        assert got["activation"] in same.get(hp["activation"], (hp["activation"],))
+        assert got["attn_activation"] in same.get(hp["attn_activation"], (hp["attn_activation"],))
+        ours = set(make_state_dict(hp, seed=1).keys())
+        theirs = set(model.state_dict().keys())
+        assert ours == theirs, ours ^ theirs
