@@ -10,16 +10,26 @@
 // Arithmetic: v_mfma_f32_32x32x2_f32 - exact fp32 (an fmaf chain), 157 TF peak.
 //
 // Tile: BM x BN per 256-thread workgroup (4 waves as WM x WN), BK = 32.
-// LDS rows are padded to 36 floats so the ds_read_b128 fragment reads of a
-// 16-lane service group land in 16 distinct 16-byte slots (conflict free).
+// LDS rows are 32 floats (128 B, no padding) with the eight 16-byte chunks of a
+// row XOR-swizzled by (row >> 1) & 7, so the ds_read_b128 fragment reads of a
+// 16-lane service group (16 consecutive rows, one logical chunk) land in 16
+// distinct 16-byte slots.  Unpadded, the double-buffered 64x64 tile takes
+// exactly 32 KiB: FIVE workgroups fit the 160 KiB of a CU (padding: four).
 // Each lane reads 4 consecutive k of its row: lanes 0-31 take k0..k0+3, lanes
 // 32-63 take k0+4..k0+7; MFMA #t pairs (k0+t, k0+4+t) for A and B alike, so
 // the k-sum is just reordered.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
 
+#ifndef VSN_LAB_TRACE
+#define VSN_LAB_TRACE 0  // tools/lab/gemm_direct.hip: per-wave phase timestamps of the k-loop (1 = on; lab builds only)
+#endif
+#ifndef VSN_LAB_ACC2
+#define VSN_LAB_ACC2 0  // lab: two interleaved accumulators on the one-accumulator tile (a ready MFMA at every issue slot)
+#endif
 #ifndef VSN_LAB_PRIO
 #define VSN_LAB_PRIO 0  // tools/lab/gemm_direct.hip: s_setprio placement experiments (0 = none, the product build)
 #endif
@@ -29,18 +39,33 @@ namespace vsn {
 // SILU: apply the activation to A on its way into LDS (one product of the read-out head); a template parameter so
 // that the ~250 VALU instructions of the exact sigmoid are not sitting in the k-loop of every other product
 // (1 = silu, 2 = any kind of the reference's table, carried in flags bits 8..).
-template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32, int PF = 1>
+//
+// What the per-wave phase trace of the 64x64 kernel (tools/lab/gemm_direct.hip, -DVSN_LAB_TRACE=1) showed and this
+// body is built around: with K = 256 a tile is only eight k-iterations long, so everything OUTSIDE the k-loop
+// (prologue 6.6 k cycles, epilogue 7.7 k, workgroup turnover 2.5 k, against 30 k in the loop) decides how many of a
+// SIMD's wave slots are inside an MFMA block at any time - the pipe saturates with three, and it had 2.3 of 4.
+//  * 32 KiB of LDS per workgroup (swizzled, unpadded rows) -> five resident workgroups per CU instead of four;
+//  * the epilogue is ~100 instructions (uniform tile base + 32-bit lane offsets, no per-row predicates on whole
+//    tiles, accumulate-mode products start their accumulator FROM C instead of adding C at the end);
+//  * fragment reads are double-buffered over the four k-steps of a tile and the LDS stores of the next tile sit in
+//    the middle of the MFMA block, so a lone wave (small launches, tails) does not expose their latency either;
+//  * global operands are addressed as uniform base + 32-bit lane offset: no 64-bit VALU arithmetic in the loop.
+template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32>
 __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, const float* __restrict__ Bt,
                                           int ldb, float* __restrict__ C, int ldc,
                                           const float* __restrict__ bias, int M, const int* __restrict__ Mptr,
                                           int Nc, int K, int flags, int ksplit, float* __restrict__ part,
                                           int block_id, float* __restrict__ smem) {
-  constexpr int LS = BK + 4;  // padded LDS row stride (floats)
-  constexpr int C4 = BK / 4;  // 16-byte chunks per tile row
+  constexpr bool SWZ = BK == 32;         // XOR-swizzled rows (BK = 32, every product instantiation) or padded rows (lab)
+  constexpr int LS = SWZ ? BK : BK + 4;  // LDS row stride (floats)
+  constexpr int C4 = BK / 4;             // 16-byte chunks per tile row
+  constexpr int KK = BK / 8;             // MFMA k-steps per tile (8 k each: lanes 0-31 take k..k+3, lanes 32-63 k+4..k+7)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
   constexpr int LA = BM * C4 / 256, LB = BN * C4 / 256;  // 16-byte loads per thread per k-tile
   constexpr int STAGE = (BM + BN) * LS;
+  // LDS float offset of logical chunk c4 of tile row r
+#define VSN_LDS_AT(r, c4) ((r) * LS + (SWZ ? (((c4) ^ (((r) >> 1) & 7)) * 4) : (c4) * 4))
 
   int Meff = M;
   if (Mptr) {
@@ -62,210 +87,281 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
+#if VSN_LAB_TRACE
+  // lab: lane 0 of every wave stamps its phases straight into `part` ([block][wave][64] dwords; ksplit must be 1)
+  unsigned* const trace = reinterpret_cast<unsigned*>(part) + ((size_t)block_id * 4 + wave) * 64;
+  int trn = 2;
+#define VSN_STAMP_AT(slot)                                                                  \
+  do {                                                                                      \
+    if (part && lane == 0) trace[slot] = (unsigned)__builtin_amdgcn_s_memtime();            \
+  } while (0)
+#define VSN_STAMP()                    \
+  do {                                 \
+    if (trn < 62) VSN_STAMP_AT(trn);   \
+    ++trn;                             \
+  } while (0)
+  if (part && lane == 0) trace[0] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);  // HW_ID[15:0]
+  if (part && lane == 0) trace[61] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 6);  // LDS_ALLOC
+  VSN_STAMP_AT(62);  // kernel entry
+#else
+#define VSN_STAMP_AT(slot)
+#define VSN_STAMP()
+#endif
   constexpr bool silu_a = SILU != 0;  // 1: silu (folds to the branch-free form), 2: kind from flags bits 8..
   const int akind = SILU == 2 ? (flags >> 8) : VSN_ACT_SILU;
-  // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce)
+  // this workgroup's K range (split-K: partial sums go to `part`, reduced by k_gemm_reduce or by the consumer)
   const int nkt_all = K / BK;
   const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
   const int nkt = kt1 - kt0;
-  const int kbase = kt0 * BK;
 
-  // PF = global-load prefetch depth of the double-buffered pipeline, in k-tiles held in registers (1 or 2)
-  f32x4 rra[PF][LA], rrb[PF][LB];
-#define VSN_GLOAD(k0) VSN_GLOAD_S(0, k0)
-#define VSN_SSTORE(buf) VSN_SSTORE_S(0, buf)
-#define VSN_GLOAD_S(SET, k0)                                                                   \
-  {                                                                                          \
-    _Pragma("unroll") for (int it = 0; it < LA; ++it) {                                      \
-      const int f_ = tid + it * 256;                                                         \
-      const int r_ = f_ / C4, c4_ = f_ % C4;                                                  \
-      int gr_ = row0 + r_;                                                                   \
-      gr_ = gr_ < Meff ? gr_ : Meff - 1; /* clamp: rows >= Meff are never stored */          \
-      rra[SET][it] = *reinterpret_cast<const f32x4*>(A + (size_t)gr_ * lda + (k0) + c4_ * 4); \
-    }                                                                                        \
-    _Pragma("unroll") for (int it = 0; it < LB; ++it) {                                      \
-      const int f_ = tid + it * 256;                                                         \
-      const int r_ = f_ / C4, c4_ = f_ % C4;                                                  \
-      rrb[SET][it] = *reinterpret_cast<const f32x4*>(Bt + (size_t)(col0 + r_) * ldb + (k0) + c4_ * 4); \
-    }                                                                                        \
+  // Global operands: one uniform base per tile, 32-bit lane offsets (rows >= Meff are clamped: never stored).
+  const float* __restrict__ Ab = A + (size_t)row0 * lda + (size_t)kt0 * BK;
+  const float* __restrict__ Bb = Bt + (size_t)col0 * ldb + (size_t)kt0 * BK;
+  unsigned aoff[LA], boff[LB];
+  int lsa[LA], lsb[LB];  // where the lane's chunks go in an LDS stage
+#pragma unroll
+  for (int it = 0; it < LA; ++it) {
+    const int f = tid + it * 256, r = f / C4, c4 = f % C4;
+    const int rr = row0 + r < Meff ? r : Meff - 1 - row0;
+    aoff[it] = (unsigned)rr * (unsigned)lda + (unsigned)(c4 * 4);
+    lsa[it] = VSN_LDS_AT(r, c4);
   }
-#define VSN_SSTORE_S(SET, buf)                                                \
-  {                                                                           \
-    float* As_ = smem + (buf) * STAGE;                                        \
-    float* Bs_ = As_ + BM * LS;                                               \
-    _Pragma("unroll") for (int it = 0; it < LA; ++it) {                       \
-      const int f_ = tid + it * 256;                                          \
-      const int r_ = f_ / C4, c4_ = f_ % C4;                                   \
-      f32x4 v_ = rra[SET][it];                                                \
-      if (silu_a) { /* activation kind (VSN_ACT_*) rides in flags bits 8.. */  \
-        v_.x = act_f(akind, v_.x);                                            \
-        v_.y = act_f(akind, v_.y);                                            \
-        v_.z = act_f(akind, v_.z);                                            \
-        v_.w = act_f(akind, v_.w);                                            \
-      }                                                                       \
-      *reinterpret_cast<f32x4*>(As_ + r_ * LS + c4_ * 4) = v_;                \
-    }                                                                         \
-    _Pragma("unroll") for (int it = 0; it < LB; ++it) {                       \
-      const int f_ = tid + it * 256;                                          \
-      const int r_ = f_ / C4, c4_ = f_ % C4;                                   \
-      *reinterpret_cast<f32x4*>(Bs_ + r_ * LS + c4_ * 4) = rrb[SET][it];      \
-    }                                                                         \
+#pragma unroll
+  for (int it = 0; it < LB; ++it) {
+    const int f = tid + it * 256, r = f / C4, c4 = f % C4;
+    boff[it] = (unsigned)r * (unsigned)ldb + (unsigned)(c4 * 4);
+    lsb[it] = BM * LS + VSN_LDS_AT(r, c4);
+  }
+  f32x4 rra[LA], rrb[LB];  // the k-tile in flight from global memory
+#define VSN_GLOAD(ktile)                                                                          \
+  {                                                                                               \
+    const float* __restrict__ Ak_ = Ab + (ktile) * BK;                                            \
+    const float* __restrict__ Bk_ = Bb + (ktile) * BK;                                            \
+    _Pragma("unroll") for (int it = 0; it < LA; ++it) rra[it] = *reinterpret_cast<const f32x4*>(Ak_ + aoff[it]); \
+    _Pragma("unroll") for (int it = 0; it < LB; ++it) rrb[it] = *reinterpret_cast<const f32x4*>(Bk_ + boff[it]); \
+  }
+#define VSN_SSTORE(stage)                                                      \
+  {                                                                            \
+    float* St_ = smem + (stage) * STAGE;                                       \
+    _Pragma("unroll") for (int it = 0; it < LA; ++it) {                        \
+      f32x4 v_ = rra[it];                                                      \
+      if (silu_a) { /* activation kind (VSN_ACT_*) rides in flags bits 8.. */   \
+        v_.x = act_f(akind, v_.x);                                             \
+        v_.y = act_f(akind, v_.y);                                             \
+        v_.z = act_f(akind, v_.z);                                             \
+        v_.w = act_f(akind, v_.w);                                             \
+      }                                                                        \
+      *reinterpret_cast<f32x4*>(St_ + lsa[it]) = v_;                           \
+    }                                                                          \
+    _Pragma("unroll") for (int it = 0; it < LB; ++it) *reinterpret_cast<f32x4*>(St_ + lsb[it]) = rrb[it]; \
   }
 
-  f32x16 acc[MI][NI];
+  // Fragment addresses: row (wm*TM + i*32 + l31) of A, (wn*TN + j*32 + l31) of B; both have the same (row >> 1) & 7,
+  // so the swizzled in-row offset of k-step kk is shared.
+  int fo[KK];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int kk = 0; kk < KK; ++kk) fo[kk] = VSN_LDS_AT(l31, kk * 2 + hi) - l31 * LS;
+  const int fra = (wm * TM + l31) * LS, frb = BM * LS + (wn * TN + l31) * LS;
 
-  // accumulate mode on the one-accumulator tile (64x64, the grouped reverse-pass products): fetch the old C values
-  // now, so that the epilogue does not wait for a memory round trip per tile
-  constexpr bool PREC = (MI * NI == 1);
+  constexpr bool PREC = (MI * NI == 1);  // one-accumulator tile (64x64, the grouped reverse-pass products)
   const bool accum = (flags & 1) != 0;
-  float cold[PREC ? 16 : 1];
-  float bvs[NI];  // the bias too: one load per lane, but at the end of the tile it is a full round trip on the tail
+  const bool acc_out = accum && ksplit == 1;
+  float bvs[NI];  // bias: fetched now - at the end of the tile it would be a full round trip on the tail
 #pragma unroll
   for (int j = 0; j < NI; ++j) bvs[j] = (bias && ksplit == 1) ? bias[col0 + wn * TN + j * 32 + l31] : 0.f;
-  if (PREC && accum && ksplit == 1) {
-    const int col = col0 + wn * TN + l31;
+
+  f32x16 acc[MI][NI];
+  if (PREC && acc_out) {
+    // accumulate mode: the accumulator STARTS from the old C values (no second pass over C in the epilogue, and
+    // no sixteen registers holding them across the k-loop)
+    const float* cp = C + (size_t)row0 * ldc + col0;
+    const int rlim = Meff - row0 - (wm * TM + 4 * hi);
+    const unsigned off = (unsigned)(wm * TM + 4 * hi) * (unsigned)ldc + (unsigned)(wn * TN + l31);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      int row = row0 + wm * TM + (r & 3) + 8 * (r >> 2) + 4 * hi;
-      row = row < Meff ? row : Meff - 1;
-      cold[r] = C[(size_t)row * ldc + col];
+      const int dr = (r & 3) + 8 * (r >> 2);
+      acc[0][0][r] = dr < rlim ? cp[off + (unsigned)dr * (unsigned)ldc] : 0.f;
     }
-  }
-  if (DB) {
-    // software pipeline: LDS holds tile kt (buffer kt&1), registers hold tile kt+1, one barrier per tile
-    VSN_GLOAD(kbase);
-    VSN_SSTORE(0);
-    {
-      const int kn = (1 < nkt ? 1 : 0) * BK + kbase;
-      VSN_GLOAD(kn);  // set 0 <- tile 1
-    }
-    if constexpr (PF == 2) {
-      const int kn = (2 < nkt ? 2 : nkt - 1) * BK + kbase;
-      VSN_GLOAD_S(PF - 1, kn);  // set 1 <- tile 2
-    }
-    __syncthreads();
   } else {
-    VSN_GLOAD(kbase);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
-  for (int kt = 0; kt < nkt; ++kt) {
+
+#if VSN_LAB_ACC2
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#endif
+#if VSN_LAB_PRIO == 5
+  {
+    // lab: one issue priority per resident workgroup of the CU (its LDS slot: LDS_ALLOC.base / 130 granules)
+    const unsigned slot = (__builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 6) & 0x1ffu) / 130u;
+    switch (slot & 3u) {
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      case 2: __builtin_amdgcn_s_setprio(2); break;
+      default: __builtin_amdgcn_s_setprio(3); break;
+    }
+  }
+#endif
+  VSN_GLOAD(0);
+  if (DB) {
+    // software pipeline: LDS stage (kt & 1) holds tile kt, registers hold tile kt+1, one barrier per tile
+    VSN_SSTORE(0);
+    if (1 < nkt) VSN_GLOAD(1);
+    __syncthreads();
+  }
+  VSN_STAMP_AT(1);  // k-loop starts
+
+#define VSN_FRAG(set, stage_, kk_)                                                                            \
+  {                                                                                                           \
+    const float* Sr_ = smem + (stage_) * STAGE + fo[kk_];                                                     \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) fa[set][i] = *reinterpret_cast<const f32x4*>(Sr_ + fra + i * 32 * LS); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) fb[set][j] = *reinterpret_cast<const f32x4*>(Sr_ + frb + j * 32 * LS); \
+  }
+  // one k-tile; ST (the LDS stage that holds it) is a compile-time constant so that every LDS address is a register
+  // plus an immediate
+  auto ktile = [&](auto stc, const int kt) __attribute__((always_inline)) {
+    constexpr int st = decltype(stc)::value;
+    VSN_STAMP();  // top of the iteration
     if (!DB) {
       VSN_SSTORE(0);
       __syncthreads();
-      const int kn = (kt + 1 < nkt ? kt + 1 : kt) * BK + kbase;
-      VSN_GLOAD(kn);
+      if (kt + 1 < nkt) VSN_GLOAD(kt + 1);
       // keep the prefetch HERE: without this hipcc sinks the loads below the MFMA block (to shorten their
       // live ranges), which exposes the full global-load latency once per k-tile
       __builtin_amdgcn_sched_barrier(0);
     }
-    const float* As = smem + (DB ? (kt & 1) : 0) * STAGE;
-    const float* Bs = As + BM * LS;
 #if VSN_LAB_PRIO == 2
     __builtin_amdgcn_s_setprio(2);  // lab: favour waves inside their MFMA block
 #endif
+    f32x4 fa[2][MI], fb[2][NI];
+    VSN_FRAG(0, st, 0);
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 a[MI], b[NI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(As + (wm * TM + i * 32 + l31) * LS + kk * 8 + hi * 4);
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn * TN + j * 32 + l31) * LS + kk * 8 + hi * 4);
+    for (int kk = 0; kk < KK; ++kk) {
+      if (kk + 1 < KK) VSN_FRAG((kk + 1) & 1, st, kk + 1);
+      const int cur = kk & 1;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+#if VSN_LAB_ACC2
+          if constexpr (PREC) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc2, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc2, 0, 0, 0);
+            continue;
+          }
+#endif
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
         }
+      if (DB && kk == KK / 2 - 1) {
+        // Half-way through the MFMA block: tile kt+1 (in registers since the last iteration) goes to the other
+        // stage - last read in iteration kt-1, a barrier ago - and the loads of tile kt+2 start.  The stores
+        // complete under the second half of the block instead of in front of the barrier.
+        __builtin_amdgcn_sched_barrier(0);
+        VSN_STAMP();
+        if (kt + 1 < nkt) {
+          VSN_SSTORE(st ^ 1);
+          if (kt + 2 < nkt) VSN_GLOAD(kt + 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // and the prefetch is issued here, not sunk below the MFMAs
+      }
     }
+    VSN_STAMP();  // MFMA block issued
 #if VSN_LAB_PRIO == 2
     __builtin_amdgcn_s_setprio(0);
 #elif VSN_LAB_PRIO == 1
-    __builtin_amdgcn_s_setprio(3);  // lab: favour waves in their LDS-store / prefetch / barrier phase
+    __builtin_amdgcn_s_setprio(3);  // lab: favour waves in their barrier phase
 #endif
-    if (DB && PF == 1 && kt + 1 < nkt) {
-      // tile kt+1 (in registers) -> the other LDS buffer (last read in iteration kt-1, a barrier ago)
-      VSN_SSTORE((kt + 1) & 1);
-      const int kn = (kt + 2 < nkt ? kt + 2 : kt + 1) * BK + kbase;
-      VSN_GLOAD(kn);
-      __builtin_amdgcn_sched_barrier(0);  // issue the prefetch before the barrier / next MFMA block
-    }
-    if constexpr (DB && PF == 2) {
-      // two tiles in flight: set (kt & 1) holds tile kt+1 (loaded two iterations ago), the other set tile kt+2;
-      // after the store the freed set fetches tile kt+3 - a load now has two MFMA blocks to land, which a workgroup
-      // that is alone on its CU (grid tails, launches of ~3 tiles per CU) needs
-      if (kt + 1 < nkt) {
-        const int kn = (kt + 3 < nkt ? kt + 3 : nkt - 1) * BK + kbase;
-        if ((kt & 1) == 0) {
-          VSN_SSTORE_S(0, (kt + 1) & 1);
-          VSN_GLOAD_S(0, kn);
-        } else {
-          VSN_SSTORE_S(PF - 1, (kt + 1) & 1);
-          VSN_GLOAD_S(PF - 1, kn);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
     __syncthreads();
+    VSN_STAMP();  // past the barrier
 #if VSN_LAB_PRIO == 1
     __builtin_amdgcn_s_setprio(0);
 #endif
+  };
+  {
+    int kt = 0;
+    if (DB) {
+      for (; kt + 1 < nkt; kt += 2) {
+        ktile(std::integral_constant<int, 0>{}, kt);
+        ktile(std::integral_constant<int, 1>{}, kt + 1);
+      }
+      if (kt < nkt) ktile(std::integral_constant<int, 0>{}, kt);
+    } else {
+      for (; kt < nkt; ++kt) ktile(std::integral_constant<int, 0>{}, kt);
+    }
   }
 
+  // Epilogue.  It runs while the other workgroups of the CU are inside their MFMA blocks and every instruction of it
+  // competes with them for issue slots: one uniform base pointer per tile, 32-bit lane offsets, and no per-row
+  // predicates on a tile that lies wholly below Meff.
+#if VSN_LAB_ACC2
+  if constexpr (PREC) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
+  }
+#endif
+  float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
+  const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
+  const bool full = row0 + BM <= Meff;
+  const bool rmw = acc_out && !PREC;  // multi-accumulator tiles add the old C here
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int col = col0 + wn * TN + j * 32 + l31;
-      const float bv = bvs[j];
+      const unsigned off = (unsigned)(wm * TM + i * 32 + 4 * hi) * ldo + (unsigned)(wn * TN + j * 32 + l31);
+      const float bv = bvs[j];  // 0 when split-K
+      if (full && !rmw) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row < Meff) {
-          if (ksplit == 1) {
-            float* cp = C + (size_t)row * ldc + col;
+        for (int r = 0; r < 16; ++r) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[i][j][r] + bv;
+      } else {
+        const int rlim = full ? BM : Meff - row0 - (wm * TM + i * 32 + 4 * hi);  // rows of this strip below Meff
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if ((r & 3) + 8 * (r >> 2) < rlim) {
+            float* cp = Ct + (off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo);
             float v = acc[i][j][r] + bv;
-            if (accum) v += PREC ? cold[r] : *cp;
+            if (rmw) v += *cp;
             *cp = v;
-          } else {
-            part[((size_t)ks * M + row) * Nc + col] = acc[i][j][r];
           }
         }
       }
     }
+  VSN_STAMP_AT(63);  // epilogue stores issued
 #undef VSN_GLOAD
 #undef VSN_SSTORE
-#undef VSN_GLOAD_S
-#undef VSN_SSTORE_S
+#undef VSN_FRAG
+#undef VSN_STAMP
+#undef VSN_STAMP_AT
+#undef VSN_LDS_AT
 }
 
-template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32, int PF = 1>
+template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32>
 __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, int M,
                                               const int* __restrict__ Mptr, int Nc, int K, int flags,
                                               int ksplit, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * (BK + 4)];
-  gemm_body<BM, BN, WM, WN, DB, SILU, BK, PF>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * (BM + BN) * (BK == 32 ? BK : BK + 4)];
+  gemm_body<BM, BN, WM, WN, DB, SILU, BK>(A, lda, Bt, ldb, C, ldc, bias, M, Mptr, Nc, K, flags, ksplit, part,
                                       (int)blockIdx.x, smem);
 }
 
 // Several independent products in ONE launch (64x64 tiles): block -> (problem, tile).  Used for the
 // per-layer groups {qkv, vector projections, edge linears}, {s_proj, o_proj}, {dX products}: on a
 // single-protein MD step the small members (N = a few hundred rows) cannot fill 256 CUs alone.
-template <int PF>
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 36];
+  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 32];  // 32 KiB: five workgroups per CU
   int b = (int)blockIdx.x, p = 0;
 #pragma unroll
   for (int q = 0; q < GemmGroup::MAXP - 1; ++q)
@@ -274,7 +370,7 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
       p = q + 1;
     }
   const GemmDesc& d = g.p[p];
-  gemm_body<64, 64, 2, 2, true, 0, 32, PF>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
+  gemm_body<64, 64, 2, 2, true, 0, 32>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
                                            d.flags, d.ksplit, d.part, b, smem);
 }
 
@@ -304,7 +400,6 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 int g_splitk_tiles = 400;   // split-K only below this many output tiles (env VSN_SPLITK_TILES; swept on Chignolin: 0:297, 200:306, 400:306, 768:301, 1200:289 steps/s)
 int g_gemm_force = 0;     // micro-benchmark aid (env VSN_GEMM_FORCE): force an experimental tile variant
-int g_gemm_pf = 1;  // global-load prefetch depth of the grouped 64x64 kernel (env VSN_GEMM_PF: 1 | 2)
 int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
 void set_gemm_profiler(GemmProfiler* p) { tl_prof = p; }
@@ -323,8 +418,6 @@ static bool gemm_env_init() {
   if (e) g_gemm_db128 = atoi(e);
   e = getenv("VSN_SPLITK_TILES");
   if (e) g_splitk_tiles = atoi(e);
-  e = getenv("VSN_GEMM_PF");
-  if (e) g_gemm_pf = atoi(e);
   e = getenv("VSN_GEMM_FORCE");
   if (e) g_gemm_force = atoi(e);
   return true;
@@ -516,8 +609,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     g.p[g.n++] = d;
   }
   if (g.n > 0) {
-    if (g_gemm_pf == 2) hipLaunchKernelGGL(k_gemm_group<2>, dim3(grid), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(k_gemm_group<1>, dim3(grid), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
   }
   for (int i = 0; i < nred; ++i) {
     const GemmDesc& d = red[i];

@@ -165,7 +165,7 @@ static double max_err(const float* dC, const float* dR, size_t n) {
 
 int main() {
   const Shape shapes[] = {{6687, 768, 256}, {3128, 1280, 256}, {6687, 512, 256}, {6687, 256, 512},
-                          {6687, 256, 768}, {3128, 256, 1280}, {391, 768, 256}, {26624, 768, 256}};
+                          {6687, 256, 768}, {3128, 256, 1280}, {391, 768, 256}, {26624, 768, 256}, {26624, 768, 2048}, {8192, 1024, 4096}};
   printf("%7s %5s %5s | %-24s %9s %8s %9s\n", "M", "Nc", "K", "kernel", "us", "TFLOP/s", "max|err|");
   for (const Shape& s : shapes) {
     const size_t na = (size_t)s.M * s.K, nb = (size_t)s.Nc * s.K, nc = (size_t)s.M * s.Nc;
@@ -198,14 +198,37 @@ int main() {
              hipLaunchKernelGGL((vsn::k_gemm<64, 64, 2, 2, true>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc,
                                 bias, s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);
            }));
+#if VSN_LAB_TRACE
+    {  // one traced launch: per-wave phase stamps -> gpurun_out/gemm_trace_<M>.csv  (block, wave, hw_id, t0, stamps...)
+      unsigned* tr;
+      hipMalloc(&tr, (size_t)grid * 4 * 64 * 4);
+      hipMemset(tr, 0, (size_t)grid * 4 * 64 * 4);
+      hipLaunchKernelGGL((vsn::k_gemm<64, 64, 2, 2, true>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc, bias,
+                         s.M, nullptr, s.Nc, s.K, 0, 1, reinterpret_cast<float*>(tr));
+      hipDeviceSynchronize();
+      std::vector<unsigned> h((size_t)grid * 4 * 64);
+      hipMemcpy(h.data(), tr, h.size() * 4, hipMemcpyDeviceToHost);
+      char fn[128];
+      snprintf(fn, sizeof fn, "gpurun_out/gemm_trace_%d_%d_%d.csv", s.M, s.Nc, s.K);
+      if (FILE* f = fopen(fn, "w")) {
+        for (int b = 0; b < grid; ++b)
+          for (int w = 0; w < 4; ++w) {
+            fprintf(f, "%d,%d", b, w);
+            for (int k = 0; k < 64; ++k) fprintf(f, ",%u", h[((size_t)b * 4 + w) * 64 + k]);
+            fprintf(f, "\n");
+          }
+        fclose(f);
+      }
+      hipFree(tr);
+    }
+#endif
 #define RUN_PROD(NAME, ...)                                                                                       \
   hipMemset(C, 0, nc * 4);                                                                                        \
   report(NAME, time_us([&] {                                                                                      \
            hipLaunchKernelGGL((vsn::k_gemm<__VA_ARGS__>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc, bias, \
                               s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                                            \
          }));
-    RUN_PROD("64x64 db pf2", 64, 64, 2, 2, true, 0, 32, 2)
-    RUN_PROD("64x64 db bk16 pf2", 64, 64, 2, 2, true, 0, 16, 2)
+    RUN_PROD("64x64 sb", 64, 64, 2, 2, false)
 #define RUN_DIRECT(PD, X)                                                                                        \
   hipMemset(C, 0, nc * 4);                                                                                       \
   report("direct pd" #PD " xcd" #X, time_us([&] {                                                                 \
