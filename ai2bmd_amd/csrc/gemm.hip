@@ -14,7 +14,9 @@
 // row XOR-swizzled by (row >> 1) & 7, so the ds_read_b128 fragment reads of a
 // 16-lane service group (16 consecutive rows, one logical chunk) land in 16
 // distinct 16-byte slots.  Unpadded, the double-buffered 64x64 tile takes
-// exactly 32 KiB: FIVE workgroups fit the 160 KiB of a CU (padding: four).
+// exactly 32 KiB (padded rows: 36 KiB).  That is still FOUR workgroups per CU,
+// not five: LDS is allocated in 1 280-byte steps (HW_REG_LDS_ALLOC reads 130
+// 256-byte granules for 32 768 bytes), so five would need <= 32 000 bytes each.
 // Each lane reads 4 consecutive k of its row: lanes 0-31 take k0..k0+3, lanes
 // 32-63 take k0+4..k0+7; MFMA #t pairs (k0+t, k0+4+t) for A and B alike, so
 // the k-sum is just reordered.
@@ -26,9 +28,6 @@
 
 #ifndef VSN_LAB_TRACE
 #define VSN_LAB_TRACE 0  // tools/lab/gemm_direct.hip: per-wave phase timestamps of the k-loop (1 = on; lab builds only)
-#endif
-#ifndef VSN_LAB_ACC2
-#define VSN_LAB_ACC2 0  // lab: two interleaved accumulators on the one-accumulator tile (a ready MFMA at every issue slot)
 #endif
 #ifndef VSN_LAB_PRIO
 #define VSN_LAB_PRIO 0  // tools/lab/gemm_direct.hip: s_setprio placement experiments (0 = none, the product build)
@@ -44,7 +43,7 @@ namespace vsn {
 // body is built around: with K = 256 a tile is only eight k-iterations long, so everything OUTSIDE the k-loop
 // (prologue 6.6 k cycles, epilogue 7.7 k, workgroup turnover 2.5 k, against 30 k in the loop) decides how many of a
 // SIMD's wave slots are inside an MFMA block at any time - the pipe saturates with three, and it had 2.3 of 4.
-//  * 32 KiB of LDS per workgroup (swizzled, unpadded rows) -> five resident workgroups per CU instead of four;
+//  * swizzled, unpadded LDS rows (32 KiB per workgroup; the fifth resident workgroup needs <= 32 000 B, see above);
 //  * the epilogue is ~100 instructions (uniform tile base + 32-bit lane offsets, no per-row predicates on whole
 //    tiles, accumulate-mode products start their accumulator FROM C instead of adding C at the end);
 //  * fragment reads are double-buffered over the four k-steps of a tile and the LDS stores of the next tile sit in
@@ -191,23 +190,6 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   }
 
-#if VSN_LAB_ACC2
-  f32x16 acc2;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-#endif
-#if VSN_LAB_PRIO == 5
-  {
-    // lab: one issue priority per resident workgroup of the CU (its LDS slot: LDS_ALLOC.base / 130 granules)
-    const unsigned slot = (__builtin_amdgcn_s_getreg((8 << 11) | (0 << 6) | 6) & 0x1ffu) / 130u;
-    switch (slot & 3u) {
-      case 0: __builtin_amdgcn_s_setprio(0); break;
-      case 1: __builtin_amdgcn_s_setprio(1); break;
-      case 2: __builtin_amdgcn_s_setprio(2); break;
-      default: __builtin_amdgcn_s_setprio(3); break;
-    }
-  }
-#endif
   VSN_GLOAD(0);
   if (DB) {
     // software pipeline: LDS stage (kt & 1) holds tile kt, registers hold tile kt+1, one barrier per tile
@@ -249,15 +231,6 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-#if VSN_LAB_ACC2
-          if constexpr (PREC) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc2, 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc2, 0, 0, 0);
-            continue;
-          }
-#endif
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
@@ -304,12 +277,6 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   // Epilogue.  It runs while the other workgroups of the CU are inside their MFMA blocks and every instruction of it
   // competes with them for issue slots: one uniform base pointer per tile, 32-bit lane offsets, and no per-row
   // predicates on a tile that lies wholly below Meff.
-#if VSN_LAB_ACC2
-  if constexpr (PREC) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] += acc2[r];
-  }
-#endif
   float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
   const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
   const bool full = row0 + BM <= Meff;
@@ -361,7 +328,7 @@ __global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int l
 // per-layer groups {qkv, vector projections, edge linears}, {s_proj, o_proj}, {dX products}: on a
 // single-protein MD step the small members (N = a few hundred rows) cannot fill 256 CUs alone.
 __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 32];  // 32 KiB: five workgroups per CU
+  __shared__ __attribute__((aligned(16))) float smem[2 * (64 + 64) * 32];  // 32 KiB
   int b = (int)blockIdx.x, p = 0;
 #pragma unroll
   for (int q = 0; q < GemmGroup::MAXP - 1; ++q)

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../ai2bmd_amd/csrc/gemm.hip"
+#include "gemm_streamk.hip"
 
 
 template <int PD, bool XCD>
@@ -222,13 +223,38 @@ int main() {
       hipFree(tr);
     }
 #endif
+    {  // persistent stream-K form of the same product (one member), G = 1024 workgroups
+      static int* cnt = nullptr;
+      static float* ws = nullptr;
+      if (!cnt) {
+        hipMalloc(&cnt, (1 << 20) * 4);
+        hipMemset(cnt, 0, (1 << 20) * 4);
+        hipMalloc(&ws, vsn::gemm_sk_ws_floats(1024) * 4);
+      }
+      vsn::set_gemm_sk_workspace(cnt, 1 << 20, ws, 1024);
+      hipMemset(C, 0, nc * 4);
+      vsn::GemmDesc d = vsn::gemm_desc(A, s.K, B, s.K, C, s.Nc, bias, s.M, nullptr, s.Nc, s.K, 0);
+      report("stream-K persistent", time_us([&] { vsn::launch_gemm_sk(0, &d, 1); }));
+    }
 #define RUN_PROD(NAME, ...)                                                                                       \
   hipMemset(C, 0, nc * 4);                                                                                        \
   report(NAME, time_us([&] {                                                                                      \
            hipLaunchKernelGGL((vsn::k_gemm<__VA_ARGS__>), dim3(grid), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc, bias, \
                               s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                                            \
          }));
-    RUN_PROD("64x64 sb", 64, 64, 2, 2, false)
+#undef RUN_PROD
+#define RUN_PROD(NAME, BM_, BN_, ...)                                                                              \
+  {                                                                                                               \
+    const int grid2 = ((s.M + BM_ - 1) / BM_) * (s.Nc / BN_);                                                      \
+    hipMemset(C, 0, nc * 4);                                                                                      \
+    report(NAME, time_us([&] {                                                                                    \
+             hipLaunchKernelGGL((vsn::k_gemm<BM_, BN_, __VA_ARGS__>), dim3(grid2), dim3(256), 0, 0, A, s.K, B, s.K, C, \
+                                s.Nc, bias, s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                              \
+           }));                                                                                                   \
+  }
+    RUN_PROD("128x64 db", 128, 64, 2, 2, true)
+    RUN_PROD("64x128 db", 64, 128, 2, 2, true)
+    RUN_PROD("128x128 db", 128, 128, 2, 2, true)
 #define RUN_DIRECT(PD, X)                                                                                        \
   hipMemset(C, 0, nc * 4);                                                                                       \
   report("direct pd" #PD " xcd" #X, time_us([&] {                                                                 \
