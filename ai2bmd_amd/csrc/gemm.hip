@@ -61,7 +61,9 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   constexpr int KK = BK / 8;             // MFMA k-steps per tile (8 k each: lanes 0-31 take k..k+3, lanes 32-63 k+4..k+7)
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int MI = TM / 32, NI = TN / 32;
-  constexpr int LA = BM * C4 / 256, LB = BN * C4 / 256;  // 16-byte loads per thread per k-tile
+  constexpr int NT = WM * WN * 64;                       // threads per workgroup (256 in every product instantiation)
+  constexpr int LA = BM * C4 / NT, LB = BN * C4 / NT;    // 16-byte loads per thread per k-tile
+  static_assert(LA * NT == BM * C4 && LB * NT == BN * C4, "tile rows must divide over the workgroup");
   constexpr int STAGE = (BM + BN) * LS;
   // LDS float offset of logical chunk c4 of tile row r
 #define VSN_LDS_AT(r, c4) ((r) * LS + (SWZ ? (((c4) ^ (((r) >> 1) & 7)) * 4) : (c4) * 4))
@@ -120,14 +122,14 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   int lsa[LA], lsb[LB];  // where the lane's chunks go in an LDS stage
 #pragma unroll
   for (int it = 0; it < LA; ++it) {
-    const int f = tid + it * 256, r = f / C4, c4 = f % C4;
+    const int f = tid + it * NT, r = f / C4, c4 = f % C4;
     const int rr = row0 + r < Meff ? r : Meff - 1 - row0;
     aoff[it] = (unsigned)rr * (unsigned)lda + (unsigned)(c4 * 4);
     lsa[it] = VSN_LDS_AT(r, c4);
   }
 #pragma unroll
   for (int it = 0; it < LB; ++it) {
-    const int f = tid + it * 256, r = f / C4, c4 = f % C4;
+    const int f = tid + it * NT, r = f / C4, c4 = f % C4;
     boff[it] = (unsigned)r * (unsigned)ldb + (unsigned)(c4 * 4);
     lsb[it] = BM * LS + VSN_LDS_AT(r, c4);
   }
@@ -313,7 +315,7 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 }
 
 template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32>
-__global__ __launch_bounds__(256) void k_gemm(const float* __restrict__ A, int lda,
+__global__ __launch_bounds__(WM * WN * 64) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
                                               float* __restrict__ C, int ldc,
                                               const float* __restrict__ bias, int M,

@@ -166,7 +166,7 @@ static double max_err(const float* dC, const float* dR, size_t n) {
 
 int main() {
   const Shape shapes[] = {{6687, 768, 256}, {3128, 1280, 256}, {6687, 512, 256}, {6687, 256, 512},
-                          {6687, 256, 768}, {3128, 256, 1280}, {391, 768, 256}, {26624, 768, 256}, {26624, 768, 2048}, {8192, 1024, 4096}};
+                          {6687, 256, 768}, {3128, 256, 1280}, {391, 768, 256}, {26624, 768, 256}, {262144, 768, 256}, {26624, 768, 2048}, {8192, 1024, 4096}};
   printf("%7s %5s %5s | %-24s %9s %8s %9s\n", "M", "Nc", "K", "kernel", "us", "TFLOP/s", "max|err|");
   for (const Shape& s : shapes) {
     const size_t na = (size_t)s.M * s.K, nb = (size_t)s.Nc * s.K, nc = (size_t)s.M * s.Nc;
@@ -222,6 +222,29 @@ int main() {
       }
       hipFree(tr);
     }
+    if (s.M >= 20000) {  // the batch tile (128x128, single LDS buffer) on the large grids
+      const int g128 = ((s.M + 127) / 128) * (s.Nc / 128);
+      unsigned* tr;
+      hipMalloc(&tr, (size_t)g128 * 4 * 64 * 4);
+      hipMemset(tr, 0, (size_t)g128 * 4 * 64 * 4);
+      hipLaunchKernelGGL((vsn::k_gemm<128, 128, 2, 2, false>), dim3(g128), dim3(256), 0, 0, A, s.K, B, s.K, C, s.Nc,
+                         bias, s.M, nullptr, s.Nc, s.K, 0, 1, reinterpret_cast<float*>(tr));
+      hipDeviceSynchronize();
+      std::vector<unsigned> h((size_t)g128 * 4 * 64);
+      hipMemcpy(h.data(), tr, h.size() * 4, hipMemcpyDeviceToHost);
+      char fn[128];
+      snprintf(fn, sizeof fn, "gpurun_out/gemm_trace128_%d_%d_%d.csv", s.M, s.Nc, s.K);
+      if (FILE* f = fopen(fn, "w")) {
+        for (int b = 0; b < g128; ++b)
+          for (int w = 0; w < 4; ++w) {
+            fprintf(f, "%d,%d", b, w);
+            for (int k = 0; k < 64; ++k) fprintf(f, ",%u", h[((size_t)b * 4 + w) * 64 + k]);
+            fprintf(f, "\n");
+          }
+        fclose(f);
+      }
+      hipFree(tr);
+    }
 #endif
     {  // persistent stream-K form of the same product (one member), G = 1024 workgroups
       static int* cnt = nullptr;
@@ -252,9 +275,19 @@ int main() {
                                 s.Nc, bias, s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                              \
            }));                                                                                                   \
   }
-    RUN_PROD("128x64 db", 128, 64, 2, 2, true)
-    RUN_PROD("64x128 db", 64, 128, 2, 2, true)
-    RUN_PROD("128x128 db", 128, 128, 2, 2, true)
+#define RUN_PROD8(NAME, BM_, BN_, WM_, WN_)                                                                        \
+  {                                                                                                               \
+    const int grid2 = ((s.M + BM_ - 1) / BM_) * (s.Nc / BN_);                                                      \
+    hipMemset(C, 0, nc * 4);                                                                                      \
+    report(NAME, time_us([&] {                                                                                    \
+             hipLaunchKernelGGL((vsn::k_gemm<BM_, BN_, WM_, WN_, true>), dim3(grid2), dim3(WM_* WN_ * 64), 0, 0, A, s.K, B, \
+                                s.K, C, s.Nc, bias, s.M, nullptr, s.Nc, s.K, 0, 1, nullptr);                       \
+           }));                                                                                                   \
+  }
+    RUN_PROD("128x128 sb (batch tile)", 128, 128, 2, 2, false)
+    RUN_PROD8("128x64 db 8 waves", 128, 64, 4, 2)
+    RUN_PROD8("64x128 db 8 waves", 64, 128, 2, 4)
+    RUN_PROD8("128x128 db 16 waves", 128, 128, 4, 4)
 #define RUN_DIRECT(PD, X)                                                                                        \
   hipMemset(C, 0, nc * 4);                                                                                       \
   report("direct pd" #PD " xcd" #X, time_us([&] {                                                                 \

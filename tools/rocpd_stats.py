@@ -92,9 +92,11 @@ def gaps(path, lo=0.3, hi=0.6):
         print(f"  p{int(q * 100):02d} {g[int(q * (n - 1))] / 1e3:.2f} us")
 
 
-def timeline(path, anchor="k_build_fragments", which=-3):
+def timeline(path, anchor="k_build_fragments", which=-12):
     """one MD step as a kernel sequence: offset of every dispatch from the step's first kernel (`anchor`),
-    duration, queue (stream) and grid - the `which`-th occurrence of the anchor (negative = from the end)"""
+    duration, queue (stream) and grid - the `which`-th occurrence of the anchor (negative = from the end; the
+    default skips bench.py's closing instrumented pass, whose five steps carry a HIP event pair per GEMM launch)"""
+    which = int(which)
     con = sqlite3.connect(path)
     cur = con.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -122,7 +124,7 @@ def timeline(path, anchor="k_build_fragments", which=-3):
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "--timeline":
-        timeline(sys.argv[1], *sys.argv[3:4])
+        timeline(sys.argv[1], *sys.argv[3:5])
         sys.exit(0)
     if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
         gaps(sys.argv[1], *[float(v) for v in sys.argv[3:5]])
