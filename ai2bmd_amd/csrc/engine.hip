@@ -22,7 +22,6 @@
 using namespace vsn;
 
 #define VSN_MAX_FRAG_ATOMS 262144  // int32 edge ids: n * max_num_neighbors must stay below 2^31
-#define VSN_GEO_W 24  // g_geo row: dE/dd (vector messages) 0..7, dE/dC 8, dE/dd (edge update) 16..23
 
 namespace {
 

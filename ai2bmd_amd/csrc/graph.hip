@@ -231,7 +231,7 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
   const long long e = gid / Rp;
   const int k = (int)(gid % Rp);
   if (e >= E) return;
-  if (k < 24) g_geo[e * 24 + k] = 0.f;  // the reverse pass accumulates dE/dd, dE/dC per edge here (Rp >= 32 > 24)
+  if (k < VSN_GEO_W) g_geo[e * VSN_GEO_W + k] = 0.f;  // the reverse pass accumulates dE/dd, dE/dC per edge here (Rp >= 32)
   const int j = src[e], i = tgt[e];
   float ex = pos[3 * j + 0] - pos[3 * i + 0];
   float ey = pos[3 * j + 1] - pos[3 * i + 1];
@@ -293,21 +293,21 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
 // and the unit-vector normalisation).  one thread per edge.
 __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restrict__ geo,
                            const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
-                           const float* __restrict__ g_geo /*[E,24]: g_d 0..7 and 16..23, g_C at 8*/, int S,
+                           const float* __restrict__ g_geo /*[E,32]: g_d 0..7, 16..23 and 24..31, g_C at 8*/, int S,
                            float* __restrict__ g_ev /*[E,4]*/) {
   const int E = *ecount;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const float* g = geo + (size_t)e * 8;
   const float dC = g[2], ux = g[3], uy = g[4], uz = g[5], rinv = g[6];
-  float gr = g_geo[(size_t)e * 24 + 8] * dC;
+  float gr = g_geo[(size_t)e * VSN_GEO_W + 8] * dC;
   const float* gb = g_rbf + (size_t)e * Rp;
   const float* db = drbf + (size_t)e * Rp;
   for (int k = 0; k < Rp; ++k) gr += gb[k] * db[k];
-  const float* gd0 = g_geo + (size_t)e * 24;
+  const float* gd0 = g_geo + (size_t)e * VSN_GEO_W;
   float gd[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) gd[k] = gd0[k] + gd0[16 + k];  // vector-message + edge-update shares
+  for (int k = 0; k < 8; ++k) gd[k] = gd0[k] + (gd0[16 + k] + gd0[24 + k]);  // vector-message + edge-update shares (two channel halves)
   const float s3 = 1.7320508075688772f;
   float gx = gd[0], gy = gd[1], gz = gd[2];
   if (S == 8) {

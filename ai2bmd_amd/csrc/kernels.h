@@ -30,12 +30,15 @@ struct GraphArgs {
   int z_limit;   // valid atomic numbers: 0 <= z < z_limit (embedding rows, atomref rows)
   int* status;   // device word: epoch of the last chunk that saw an atomic number out of range (never cleared)
   int epoch;     // this chunk's epoch: *status == epoch <=> this chunk is invalid
-  float* g_geo;  // [E,24] reverse-pass accumulators, cleared per live edge by k_edge_geom
+  float* g_geo;  // [E,VSN_GEO_W] reverse-pass accumulators, cleared per live edge by k_edge_geom
   float* geo;   // [E,8]  r, C, dC, ux, uy, uz, 1/r, 0
   float* d;     // [E,8]  spherical harmonics (first S used)
   float* rbf;   // [E,Rp]
   float* drbf;  // [E,Rp]
 };
+
+// g_geo row: dE/dd (vector messages) 0..7, dE/dC 8, dE/dd (edge update) 16..23 and 24..31 (one group per channel half)
+#define VSN_GEO_W 32
 
 // Everything the per-layer kernels need (one chunk).
 struct Dims {

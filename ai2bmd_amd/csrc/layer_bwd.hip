@@ -14,6 +14,8 @@
 // Sums over a node's IN-edges ("T" kernels, CSR by target) and over its
 // OUT-edges ("S" kernels, perm/colptr by source) are register accumulations by
 // one wave per node in a fixed order - no atomics, bit-reproducible.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -79,6 +81,7 @@ namespace vsn {
     }                                                                    \
   } while (0)
 
+int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
 // small batches (one protein per MD step): several waves per node
 static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
 static inline int node_grid(int N, int wpn) {
@@ -149,25 +152,31 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // wd = u1.u2 + a1 a2 cc ; df = silu(pf) wd
 // g_pf = g_f wd silu'(pf) ; g_wd = g_f silu(pf)
 // g_wt_i = sum_e g_wd (u2 + a2 cc d) ; g_d += sum_c g_wd (cc (a2 u1 + a1 u2) + 2 a1 a2 d)
-template <int V, int S, int WPN, bool GEN>
+// CS = 2: TWO waves per node, each owning half of the channels (V = H / 128 per lane).  The kernel holds three
+// [S][V] register blocks (wt, gwt, u2): at V = 4, S = 8 that is 164-202 VGPRs, two or three waves per SIMD, and it ran
+// 3.4x longer than its source-side twin (86 VGPRs).  The channels are independent except for the S per-edge
+// dE/dd sums, which each half adds into its own eight slots of the g_geo row (16..23 and 24..31; k_bwd_geom adds them).
+template <int V, int S, int WPN, bool GEN, int CS = 1>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
+  const int half = CS == 1 ? 0 : (int)blockIdx.y;
+  const int co = half * 64 * V;  // first channel of this wave's share
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V], gwt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, wt[s]);
+      ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, wt[s]);
 #pragma unroll
       for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
     }
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
-      const float geo_old = lane < S ? g_geo[(size_t)e * 24 + 16 + lane] : 0.f;  // fetched early, see k_bwd_vecmsg_T
+      const float geo_old = lane < S ? g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] : 0.f;  // fetched early, see k_bwd_vecmsg_T
       float u2[S][V], dd[S];
       float dot[V], a1[V], a2[V];
 #pragma unroll
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
       float cc = -2.0f;
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        ldrow<V>(vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, u2[s]);
+        ldrow<V>(vp + ((size_t)j * S + s) * 5 * H + 4 * H + co, lane, u2[s]);
         dd[s] = D.d[(size_t)e * 8 + s];
         cc += dd[s] * dd[s];
 #pragma unroll
@@ -186,8 +195,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
         }
       }
       float pf[V], gf[V], gpf[V], gwd[V];
-      ldrow<V>(pe + (size_t)e * 3 * H + 2 * H, lane, pf);
-      ldrow<V>(g_f + (size_t)e * H, lane, gf);
+      ldrow<V>(pe + (size_t)e * 3 * H + 2 * H + co, lane, pf);
+      ldrow<V>(g_f + (size_t)e * H + co, lane, gf);
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         float sp, dsp;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
         gpf[c] = gf[c] * wd * dsp;
         gwd[c] = gf[c] * sp;
       }
-      strow<V>(g_pe + (size_t)e * 3 * H + 2 * H, lane, gpf);
+      strow<V>(g_pe + (size_t)e * 3 * H + 2 * H + co, lane, gpf);
       constexpr int P = S <= 4 ? 4 : 8;
       float pp[P];
 #pragma unroll
@@ -213,12 +222,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
       }
       // the S per-component sums over the wave in ONE multi-value butterfly (was: S separate 6-step reductions)
       const float mine = wave_multi_sum<P>(pp, lane);
-      if (lane < S) g_geo[(size_t)e * 24 + 16 + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
+      if (lane < S) g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
     }
     node_reduce<V, S, WPN>(gwt, smem, lane, sub);
     if (sub == 0) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H, lane, gwt[s]);
+      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, gwt[s]);
     }
   }
 }
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
       const int j = edge_cache_get(srcc, D.src, e, e0);
       // the running dE/dd of this edge: fetched with the other operands, not after the reductions (a load that is
       // issued only when the sum is ready stalls the wave for a full memory round trip per edge)
-      const float geo_old = lane < S ? g_geo[(size_t)e * 24 + lane] : 0.f;
+      const float geo_old = lane < S ? g_geo[(size_t)e * VSN_GEO_W + lane] : 0.f;
       float t1[V], t2[V], s2[V], d1[V], d2[V];
       ldrow<V>(tpre + (size_t)e * 2 * H, lane, t1);
       ldrow<V>(tpre + (size_t)e * 2 * H + H, lane, t2);
@@ -321,7 +330,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
         pp[s] = p;
       }
       const float mine = wave_multi_sum<P>(pp, lane);  // lane s < S: sum over the wave of component s
-      if (lane < S) g_geo[(size_t)e * 24 + lane] = geo_old + mine;
+      if (lane < S) g_geo[(size_t)e * VSN_GEO_W + lane] = geo_old + mine;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
         gs1[c] *= d1[c];
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
       const float C = D.geo[(size_t)e * 8 + 1];
-      const float gC_old = lane == 0 ? g_geo[(size_t)e * 24 + 8] : 0.f;  // fetched early, see k_bwd_vecmsg_T
+      const float gC_old = lane == 0 ? g_geo[(size_t)e * VSN_GEO_W + 8] : 0.f;  // fetched early, see k_bwd_vecmsg_T
       float k[V], v[V], pk[V], pv[V], gm[V];
       ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
       ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
       const float gsat = ga * dssat * C;
       const bool head_lead = (lane & (lph - 1)) == 0;
       const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
-      if (lane == 0) g_geo[(size_t)e * 24 + 8] = gC_old + gC;
+      if (lane == 0) g_geo[(size_t)e * VSN_GEO_W + 8] = gC_old + gC;
       if (head_lead) {
         sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
         sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
@@ -837,7 +846,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
       }
       strow<V>(g_pp + (size_t)e * 2 * H, lane, gph);
       p = wave_sum(p);
-      if (lane == 0) g_geo[(size_t)e * 24 + 8] += p;
+      if (lane == 0) g_geo[(size_t)e * VSN_GEO_W + 8] += p;
     }
   }
 }
@@ -867,7 +876,40 @@ int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, cons
 int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
                            float* g_pe, float* g_vp, float* g_geo) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH_ACT(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
+  const int V = D.H / 64;
+  static const bool env_read = [] {
+    if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
+    return true;
+  }();
+  (void)env_read;
+  if (g_split_channels && (V & 1) == 0 && D.S == 8) {
+    // two waves per node, half the channels each (see the kernel)
+    const int w = pick_wpn(D.N);
+    const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+    const dim3 grid(node_grid(D.N, w), 2);
+    const size_t lds = node_lds(w, D.S, V / 2);
+#define VSN_EUT(VH)                                                                                                   \
+  do {                                                                                                                \
+    if (w == 1) {                                                                                                     \
+      if (gen) k_bwd_edge_update_T<VH, 8, 1, true, 2><<<grid, node_block(w), lds, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo); \
+      else k_bwd_edge_update_T<VH, 8, 1, false, 2><<<grid, node_block(w), lds, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo);    \
+    } else {                                                                                                          \
+      if (gen)                                                                                                        \
+        k_bwd_edge_update_T<VH, 8, VSN_WPN_SMALL, true, 2><<<grid, node_block(w), lds, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo); \
+      else                                                                                                            \
+        k_bwd_edge_update_T<VH, 8, VSN_WPN_SMALL, false, 2><<<grid, node_block(w), lds, st>>>(D, vp, pe, g_f, g_pe, g_vp, g_geo); \
+    }                                                                                                                 \
+  } while (0)
+    switch (V / 2) {
+      case 1: VSN_EUT(1); break;
+      case 2: VSN_EUT(2); break;
+      case 3: VSN_EUT(3); break;
+      default: VSN_EUT(4); break;
+    }
+#undef VSN_EUT
+  } else {
+    VSN_LAUNCH_ACT(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
+  }
   VSN_LAUNCH_ACT(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
   return 0;
 }

@@ -157,8 +157,8 @@ def main(name):
     cmp("g_phi", gpp[:, :H], t(b["g_phi"]))
     cmp("g_psi", gpp[:, H:], t(b["g_psi"]))
     cmp("g_rbf", rd("g_rbf").reshape(E_, Rp)[:, :R], t(b["g_rbf"]))
-    gg = rd("g_geo").reshape(E_, 24)
-    cmp("g_d", gg[:, :S] + gg[:, 16:16 + S], t(b["g_d"]))
+    gg = rd("g_geo").reshape(E_, 32)
+    cmp("g_d", gg[:, :S] + gg[:, 16:16 + S] + gg[:, 24:24 + S], t(b["g_d"]))
     cmp("g_C", gg[:, 8], t(b["g_C"]))
     cmp("g_ev", rd("g_ev").reshape(E_, 4)[:, :3], t(b["g_ev"]))
     cmp("F", f_out.cpu().numpy(), F)
