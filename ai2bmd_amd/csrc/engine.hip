@@ -857,8 +857,8 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (side_bw) {
       HIPCHK(c, hipEventRecord(c->ev_fork, st));
       HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-      if (!last) RC(launch_bwd_edge_update(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo));
-      RC(launch_bwd_vecmsg_S(c->side, D, c->g_vec, b.tpre, c->g_vh));
+      if (!last) RC(launch_bwd_side(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo, c->g_vec, b.tpre, c->g_vh));
+      else RC(launch_bwd_vecmsg_S(c->side, D, c->g_vec, b.tpre, c->g_vh));
       HIPCHK(c, hipEventRecord(c->ev_join, c->side));
       RC(launch_bwd_vecmsg(st, D, c->g_vec, b.vh, b.tpre, c->g_t, nullptr, c->g_geo));
     } else {

@@ -151,6 +151,8 @@ int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const flo
 // ---- reverse ----
 int launch_bwd_node_update(hipStream_t st, const Dims& D, const float* g_x, const float* g_vec, const float* vp,
                            const float* o, float* g_o, float* g_vp);
+int launch_bwd_side(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f, float* g_pe,
+                    float* g_vp, float* g_geo, const float* g_vec, const float* tpre, float* g_vh);
 int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f,
                            float* g_pe, float* g_vp, float* g_geo);
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,

@@ -81,7 +81,13 @@ namespace vsn {
     }                                                                    \
   } while (0)
 
+int g_fuse_side = 1;  // reverse-pass side kernels of a layer as one launch at single-protein sizes (env VSN_FUSE_SIDE=0: three)
 int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
+static const bool g_bwd_env_read = [] {  // A/B switches, read once when the library is loaded
+  if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
+  if (const char* e = getenv("VSN_FUSE_SIDE")) g_fuse_side = atoi(e);
+  return true;
+}();
 // small batches (one protein per MD step): several waves per node
 static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
 static inline int node_grid(int N, int wpn) {
@@ -157,14 +163,15 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // 3.4x longer than its source-side twin (86 VGPRs).  The channels are independent except for the S per-edge
 // dE/dd sums, which each half adds into its own eight slots of the g_geo row (16..23 and 24..31; k_bwd_geom adds them).
 template <int V, int S, int WPN, bool GEN, int CS = 1>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
-    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
-    float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const float* __restrict__ vp,
+                                                       const float* __restrict__ pe, const float* __restrict__ g_f,
+                                                       float* __restrict__ g_pe, float* __restrict__ g_vp,
+                                                       float* __restrict__ g_geo, float* __restrict__ smem,
+                                                       const int bid, const int nblk) {
   const int H = D.H;
   const int half = CS == 1 ? 0 : (int)blockIdx.y;
   const int co = half * 64 * V;  // first channel of this wave's share
-  VSN_NODE_LOOP(i, D.N, WPN) {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V], gwt[S][V];
@@ -232,14 +239,22 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
   }
 }
 
+template <int V, int S, int WPN, bool GEN, int CS = 1>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
+    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
+    float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_edge_update_T_body<V, S, WPN, GEN, CS>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---- adjoint of the edge update, source side: g_ws_j = sum_{e: src=j} g_wd (u1 + a1 cc d) ----
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
-    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
-    float* __restrict__ g_vp) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const float* __restrict__ vp,
+                                                       const float* __restrict__ pe, const float* __restrict__ g_f,
+                                                       float* __restrict__ g_vp, float* __restrict__ smem,
+                                                       const int bid, const int nblk) {
   const int H = D.H;
-  VSN_NODE_LOOP(j, D.N, WPN) {
+  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
     const int permc = edge_cache_load(D.perm, t0, t1, lane);
     const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
@@ -279,6 +294,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
       for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
     }
   }
+}
+
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
+    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
+    float* __restrict__ g_vp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- adjoint of the vector messages, target side -----------------------------------
@@ -344,11 +367,11 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
 
 // ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
-    Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __restrict__ g_vec,
+                                                  const float* __restrict__ tpre, float* __restrict__ g_vh,
+                                                  float* __restrict__ smem, const int bid, const int nblk) {
   const int H = D.H;
-  VSN_NODE_LOOP(j, D.N, WPN) {
+  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
     const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
     const int permc = edge_cache_load(D.perm, t0, t1, lane);
     const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
@@ -378,6 +401,30 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
       for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
     }
   }
+}
+
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
+    Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The three reverse-pass kernels that do not depend on a layer's main chain (edge-update adjoint, both sides, and the
+// source side of the vector messages), as ONE launch: blocks [0,G) target side, [G,2G) source side, [2G,3G) vector
+// messages.  They are independent of each other (own outputs, own g_geo slots) and latency-bound at single-protein
+// sizes: side by side they take as long as the longest, and the step has two launches less per layer.
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_side(
+    Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
+    float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo, const float* __restrict__ g_vec,
+    const float* __restrict__ tpre, float* __restrict__ g_vh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = (int)gridDim.x / 3;
+  const int b = (int)blockIdx.x;
+  if (b < G) bwd_edge_update_T_body<V, S, WPN, GEN, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b, G);
+  else if (b < 2 * G) bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, b - G, G);
+  else bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, b - 2 * G, G);
 }
 
 // ---- adjoint of attention / scalar message, target side ---------------------------
@@ -877,12 +924,9 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
                            float* g_pe, float* g_vp, float* g_geo) {
   if (D.N <= 0) return 0;
   const int V = D.H / 64;
-  static const bool env_read = [] {
-    if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
-    return true;
-  }();
-  (void)env_read;
-  if (g_split_channels && (V & 1) == 0 && D.S == 8) {
+  // batches only: with eight waves per node already (single-protein sizes) the per-wave fixed work doubles for nothing
+  // (Chignolin: 46.8 vs 40.4 us per launch); VSN_SPLIT_CH=2 forces it there too
+  if (g_split_channels && (V & 1) == 0 && D.S == 8 && (pick_wpn(D.N) == 1 || g_split_channels > 1)) {
     // two waves per node, half the channels each (see the kernel)
     const int w = pick_wpn(D.N);
     const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
@@ -911,6 +955,23 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
     VSN_LAUNCH_ACT(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
   }
   VSN_LAUNCH_ACT(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
+  return 0;
+}
+// edge-update adjoint (both sides) + source side of the vector messages; one launch at single-protein sizes
+int launch_bwd_side(hipStream_t st, const Dims& D, const float* vp, const float* pe, const float* g_f, float* g_pe,
+                    float* g_vp, float* g_geo, const float* g_vec, const float* tpre, float* g_vh) {
+  if (D.N <= 0) return 0;
+  const int w = pick_wpn(D.N);
+  if (w == 1 || !g_fuse_side) {
+    int rc = launch_bwd_edge_update(st, D, vp, pe, g_f, g_pe, g_vp, g_geo);
+    if (rc) return rc;
+    VSN_LAUNCH_ACT(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
+    return 0;
+  }
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_side,
+                   <<<3 * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
+                       D, vp, pe, g_f, g_pe, g_vp, g_geo, g_vec, tpre, g_vh));
   return 0;
 }
 int launch_bwd_vecmsg(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
