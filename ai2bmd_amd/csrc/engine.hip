@@ -853,8 +853,15 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // side stream: the edge-update adjoints (need g_f, vp, pe) and the source side of the vector messages
     // (needs g_vec, tpre) do not depend on this layer's main chain; they are joined before the dX products.
     // (edge_update_T accumulates its dE/dd into its own g_geo slots 16..23, so it cannot race vecmsg_T.)
-    const bool side_bw = (c->overlap & 2) && !c->debug && !l0;
-    if (side_bw) {
+    // single-protein sizes: no second stream at all - the same kernels ride in two launches of the main chain
+    // (k_bwd_hf1 before the g_m / g_A products, k_bwd_hf2 after them); a fork/join costs ~7 us on the main stream at
+    // each end, every layer
+    const bool streamless = (c->overlap & 2) && !c->debug && !l0 && bwd_streamless_ok(D);
+    const bool side_bw = (c->overlap & 2) && !c->debug && !l0 && !streamless;
+    if (streamless) {
+      RC(launch_bwd_hf1(st, D, c->g_vec, b.vh, b.tpre, c->g_t, c->g_geo, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_vh,
+                        !last));
+    } else if (side_bw) {
       HIPCHK(c, hipEventRecord(c->ev_fork, st));
       HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
       if (!last) RC(launch_bwd_side(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo, c->g_vec, b.tpre, c->g_vh));
@@ -887,7 +894,11 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       }
       RC(launch_gemm_group(st, gd, 2));
     }
-    RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts));
+    if (streamless && !last)
+      RC(launch_bwd_hf2(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts, b.vp,
+                        c->g_f, c->g_vp));
+    else
+      RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts));
     snapshot(c, st, "g_m", l, c->g_m, (size_t)Emax * H);
     snapshot(c, st, "g_pe", l, c->g_pe, (size_t)Emax * 3 * H);
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);

@@ -164,6 +164,13 @@ struct Parts {
   size_t stride;
   int n;  // 0: not split, read the plain array
 };
+bool bwd_streamless_ok(const Dims& D);
+int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre, float* g_t,
+                   float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
+                   float* g_vh, bool with_edge_update);
+int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
+                   float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts,
+                   const float* vp, const float* g_f, float* g_vp);
 // g_m_parts / g_A_parts: when n > 0 the incoming dE/dm rows / dE/dA rows are read as sums of those slices
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts = Parts{nullptr, 0, 0},

@@ -81,7 +81,8 @@ namespace vsn {
     }                                                                    \
   } while (0)
 
-int g_fuse_side = 1;  // reverse-pass side kernels of a layer as one launch at single-protein sizes (env VSN_FUSE_SIDE=0: three)
+int g_fuse_side = 2;  // single-protein sizes, reverse pass (env VSN_FUSE_SIDE): 2 = no second stream, the side kernels ride in
+                      // main-chain launches (k_bwd_hf1/2); 1 = one fused side-stream launch per layer; 0 = three
 int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
 static const bool g_bwd_env_read = [] {  // A/B switches, read once when the library is loaded
   if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // [S][V] register blocks (wt, gwt, u2): at V = 4, S = 8 that is 164-202 VGPRs, two or three waves per SIMD, and it ran
 // 3.4x longer than its source-side twin (86 VGPRs).  The channels are independent except for the S per-edge
 // dE/dd sums, which each half adds into its own eight slots of the g_geo row (16..23 and 24..31; k_bwd_geom adds them).
-template <int V, int S, int WPN, bool GEN, int CS = 1>
+// PART: 0 = all of it; 1 = the per-edge outputs only (g_pf, dE/dd); 2 = the per-node sum g_wt only.  At single-protein
+// sizes the two halves ride in different launches of the main chain (k_bwd_hf1 / k_bwd_hf2) - each re-reads u2.
+template <int V, int S, int WPN, bool GEN, int CS = 1, int PART = 0>
 __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const float* __restrict__ vp,
                                                        const float* __restrict__ pe, const float* __restrict__ g_f,
                                                        float* __restrict__ g_pe, float* __restrict__ g_vp,
@@ -177,13 +180,20 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
     float wt[S][V], gwt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-      ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, wt[s]);
+      if constexpr (PART != 2) {
+        ldrow<V>(vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, wt[s]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < V; ++c) wt[s][c] = 0.f;  // unused (dead code below)
+      }
 #pragma unroll
       for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
     }
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
-      const float geo_old = lane < S ? g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] : 0.f;  // fetched early, see k_bwd_vecmsg_T
+      float geo_old = 0.f;
+      if constexpr (PART != 2)  // fetched early, see k_bwd_vecmsg_T
+        geo_old = lane < S ? g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] : 0.f;
       float u2[S][V], dd[S];
       float dot[V], a1[V], a2[V];
 #pragma unroll
@@ -212,7 +222,7 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
         gpf[c] = gf[c] * wd * dsp;
         gwd[c] = gf[c] * sp;
       }
-      strow<V>(g_pe + (size_t)e * 3 * H + 2 * H + co, lane, gpf);
+      if constexpr (PART != 2) strow<V>(g_pe + (size_t)e * 3 * H + 2 * H + co, lane, gpf);
       constexpr int P = S <= 4 ? 4 : 8;
       float pp[P];
 #pragma unroll
@@ -222,15 +232,19 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
         float p = 0.f;
 #pragma unroll
         for (int c = 0; c < V; ++c) {
-          gwt[s][c] += gwd[c] * (u2[s][c] + a2[c] * cc * dd[s]);
-          p += gwd[c] * (cc * (a2[c] * wt[s][c] + a1[c] * u2[s][c]) + 2.0f * a1[c] * a2[c] * dd[s]);
+          if constexpr (PART != 1) gwt[s][c] += gwd[c] * (u2[s][c] + a2[c] * cc * dd[s]);
+          if constexpr (PART != 2)
+            p += gwd[c] * (cc * (a2[c] * wt[s][c] + a1[c] * u2[s][c]) + 2.0f * a1[c] * a2[c] * dd[s]);
         }
         pp[s] = p;
       }
-      // the S per-component sums over the wave in ONE multi-value butterfly (was: S separate 6-step reductions)
-      const float mine = wave_multi_sum<P>(pp, lane);
-      if (lane < S) g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
+      if constexpr (PART != 2) {
+        // the S per-component sums over the wave in ONE multi-value butterfly (was: S separate 6-step reductions)
+        const float mine = wave_multi_sum<P>(pp, lane);
+        if (lane < S) g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
+      }
     }
+    if constexpr (PART == 1) continue;
     node_reduce<V, S, WPN>(gwt, smem, lane, sub);
     if (sub == 0) {
 #pragma unroll
@@ -308,11 +322,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
 // mv_e[s] = vh_j[s] s1 + d_s s2 ; g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_s
 // g_t = [g_s1 silu'(t1) | g_s2 silu'(t2)] ; g_d[s] += sum_c g_vec_i[s] s2
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
-    Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
-    float* __restrict__ g_t, float* __restrict__ g_geo) {
+__device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __restrict__ g_vec,
+                                                  const float* __restrict__ vh, const float* __restrict__ tpre,
+                                                  float* __restrict__ g_t, float* __restrict__ g_geo, const int bid,
+                                                  const int nblk) {
   const int H = D.H;
-  VSN_NODE_LOOP(i, D.N, WPN) {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float gv[S][V];
@@ -363,6 +378,13 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
       strow<V>(g_t + (size_t)e * 2 * H + H, lane, gs2);
     }
   }
+}
+
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
+    Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
+    float* __restrict__ g_t, float* __restrict__ g_geo) {
+  bwd_vecmsg_T_body<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
@@ -432,15 +454,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_side(
 // g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a silu'(sat) C ; g_C += sum_h g_a silu(sat)
 // g_pk = g_sat q_i k_j silu'(pk) ; g_pv = gm v_j a silu'(pv) ; g_q_i = sum_e g_sat k_j dk
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
-    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
-    float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
-    float* __restrict__ g_geo, Parts mp, Parts ap) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void bwd_attn_T_body(const Dims& D, const float* __restrict__ qkv,
+                                                const float* __restrict__ pe, const float* __restrict__ g_A,
+                                                float* __restrict__ g_m, float* __restrict__ g_pe,
+                                                float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
+                                                float* __restrict__ g_geo, const Parts mp, const Parts ap,
+                                                float* __restrict__ smem, const int bid, const int nblk) {
   const int H = D.H;
   const int nh = D.nh;
   const int lph = 64 / nh;
-  VSN_NODE_LOOP(i, D.N, WPN) {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], gA[V], gq[1][V];
@@ -528,6 +551,54 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
     node_reduce<V, 1, WPN>(gq, smem, lane, sub);
     if (sub == 0) strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq[0]);
   }
+}
+
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
+    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
+    float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
+    float* __restrict__ g_geo, Parts mp, Parts ap) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  bwd_attn_T_body<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, (int)blockIdx.x,
+                                  (int)gridDim.x);
+}
+
+// Single-protein sizes, no second stream: the reverse kernels of a layer that do not feed each other share launches
+// of the MAIN chain (a fork/join through events costs ~7 us on the main stream at each end, every layer).
+//   k_bwd_hf1: [0,G) vector messages target side | [G,2G) edge update, per-edge half | [2G,3G) edge update source
+//              side | [3G,4G) vector messages source side          (before the g_m / g_A products)
+//   k_bwd_hf2: [0,G) attention target side | [G,2G) edge update, per-node half (after them)
+// with_eu = 0 (the last layer has no edge update): hf1 = {vector messages, both sides}; hf2 is not used.
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf1(
+    Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
+    float* __restrict__ g_t, float* __restrict__ g_geo, const float* __restrict__ vp, const float* __restrict__ pe,
+    const float* __restrict__ g_f, float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_vh,
+    int with_eu) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = (int)gridDim.x / (with_eu ? 4 : 2);
+  const int b = (int)blockIdx.x;
+  if (b < G) {
+    bwd_vecmsg_T_body<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, b, G);
+  } else if (!with_eu || b >= 3 * G) {
+    bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, b - (with_eu ? 3 * G : G), G);
+  } else if (b < 2 * G) {
+    bwd_edge_update_T_body<V, S, WPN, GEN, 1, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b - G, G);
+  } else {
+    bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, b - 2 * G, G);
+  }
+}
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf2(
+    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
+    float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
+    float* __restrict__ g_geo, Parts mp, Parts ap, const float* __restrict__ vp, const float* __restrict__ g_f,
+    float* __restrict__ g_vp) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = (int)gridDim.x >> 1;
+  const int b = (int)blockIdx.x;
+  if (b < G) bwd_attn_T_body<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, b, G);
+  else bwd_edge_update_T_body<V, S, WPN, GEN, 1, 2>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b - G, G);
 }
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
@@ -955,6 +1026,30 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
     VSN_LAUNCH_ACT(k_bwd_edge_update_T, D.S, D, vp, pe, g_f, g_pe, g_vp, g_geo);
   }
   VSN_LAUNCH_ACT(k_bwd_edge_update_S, D.S, D, vp, pe, g_f, g_vp);
+  return 0;
+}
+// the streamless reverse chain of a layer at single-protein sizes (see k_bwd_hf1 / k_bwd_hf2); false = not applicable
+bool bwd_streamless_ok(const Dims& D) { return g_fuse_side >= 2 && pick_wpn(D.N) != 1 && D.N > 0; }
+int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre, float* g_t,
+                   float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
+                   float* g_vh, bool with_edge_update) {
+  const int w = pick_wpn(D.N);
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const int with_eu = with_edge_update ? 1 : 0;
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf1,
+                   <<<(with_eu ? 4 : 2) * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
+                       D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu));
+  return 0;
+}
+int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
+                   float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts,
+                   const float* vp, const float* g_f, float* g_vp) {
+  const int w = pick_wpn(D.N);
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf2,
+                   <<<2 * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
+                       D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp));
+  VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
   return 0;
 }
 // edge-update adjoint (both sides) + source side of the vector messages; one launch at single-protein sizes
