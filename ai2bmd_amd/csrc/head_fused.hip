@@ -15,7 +15,9 @@ namespace vsn {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-#define HF_T 8          // nodes per workgroup
+#ifndef HF_T
+#define HF_T 8          // nodes per workgroup (A/B builds: -DHF_T=4)
+#endif
 #define HF_WAVES 16     // 1024 threads: 4 waves per SIMD of the one workgroup a CU holds (LDS-bound occupancy)
 
 // Out[r][n] = sum_k A[r][k] * W[n][k] (+ bias[n]) for r < M, n < Nc.  A, Out in LDS (row strides lda, ldo), W global

@@ -22,7 +22,9 @@
 namespace vsn {
 
 // template dispatch on V = H/64 (1,2,4), S (3,8) and WPN (1 or VSN_WPN_SMALL)
-#define VSN_WPN_SMALL 8
+#ifndef VSN_WPN_SMALL
+#define VSN_WPN_SMALL 8  // waves cooperating on one node at single-protein sizes (A/B builds: -DVSN_WPN_SMALL=4)
+#endif
 #define VSN_DISPATCH3(V_, S_, W_, FN, ...)                              \
   do {                                                                   \
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
@@ -245,10 +247,18 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
       }
     }
     if constexpr (PART == 1) continue;
-    node_reduce<V, S, WPN>(gwt, smem, lane, sub);
-    if (sub == 0) {
+    if constexpr (WPN > 1 && S <= WPN && V <= 4) {
+      // reduce-SCATTER: wave s ends up with the node total of component s and stores its own row (wave 0 summing
+      // and storing all S rows alone while seven waves idle was ~20 % of k_bwd_hf1 at single-protein sizes)
+      float tot[V];
+      node_reduce_scatter<V, S, WPN>(gwt, tot, smem, lane, sub);
+      if (sub < S) strow<V>(g_vp + ((size_t)i * S + sub) * 5 * H + 3 * H + co, lane, tot);
+    } else {
+      node_reduce<V, S, WPN>(gwt, smem, lane, sub);
+      if (sub == 0) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, gwt[s]);
+        for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)i * S + s) * 5 * H + 3 * H + co, lane, gwt[s]);
+      }
     }
   }
 }
@@ -302,10 +312,16 @@ __device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const floa
 #pragma unroll
         for (int c = 0; c < V; ++c) gws[s][c] += gwd[c] * (u1[s][c] + a1[c] * cc * dd[s]);
     }
-    node_reduce<V, S, WPN>(gws, smem, lane, sub);
-    if (sub == 0) {
+    if constexpr (WPN > 1 && S <= WPN && V <= 4) {
+      float tot[V];
+      node_reduce_scatter<V, S, WPN>(gws, tot, smem, lane, sub);
+      if (sub < S) strow<V>(g_vp + ((size_t)j * S + sub) * 5 * H + 4 * H, lane, tot);
+    } else {
+      node_reduce<V, S, WPN>(gws, smem, lane, sub);
+      if (sub == 0) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
+        for (int s = 0; s < S; ++s) strow<V>(g_vp + ((size_t)j * S + s) * 5 * H + 4 * H, lane, gws[s]);
+      }
     }
   }
 }
@@ -417,10 +433,16 @@ __device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __
         for (int c = 0; c < V; ++c) acc[s][c] += gv[c] * s1[c];
       }
     }
-    node_reduce<V, S, WPN>(acc, smem, lane, sub);
-    if (sub == 0) {
+    if constexpr (WPN > 1 && S <= WPN && V <= 4) {
+      float tot[V];
+      node_reduce_scatter<V, S, WPN>(acc, tot, smem, lane, sub);
+      if (sub < S) strow<V>(g_vh + ((size_t)j * S + sub) * H, lane, tot);
+    } else {
+      node_reduce<V, S, WPN>(acc, smem, lane, sub);
+      if (sub == 0) {
 #pragma unroll
-      for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
+        for (int s = 0; s < S; ++s) strow<V>(g_vh + ((size_t)j * S + s) * H, lane, acc[s]);
+      }
     }
   }
 }

@@ -18,7 +18,9 @@
 namespace vsn {
 
 // template dispatch on V = H/64 (1,2,4), S (3,8) and WPN (1 or VSN_WPN_SMALL)
+#ifndef VSN_WPN_SMALL
 #define VSN_WPN_SMALL 8
+#endif
 #define VSN_DISPATCH3(V_, S_, W_, FN, ...)                              \
   do {                                                                   \
     if ((W_) == 1) FN<V_, S_, 1> __VA_ARGS__;                            \
