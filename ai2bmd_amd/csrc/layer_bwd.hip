@@ -591,8 +591,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
 //              side | [3G,4G) vector messages source side          (before the g_m / g_A products)
 //   k_bwd_hf2: [0,G) attention target side | [G,2G) edge update, per-node half (after them)
 // with_eu = 0 (the last layer has no edge update): hf1 = {vector messages, both sides}; hf2 is not used.
+// Occupancy: the straight kernel needs 140 VGPRs = three waves per SIMD, i.e. ONE eight-wave workgroup per CU, and its
+// 4 N workgroups ran in six rounds on a Chignolin step.  Asking for four waves per SIMD makes hipcc schedule the row
+// loads less eagerly: 128 VGPRs, no spills, two workgroups per CU (Chignolin 431 -> 438 steps/s).  [Cutting the
+// registers by walking the channels in two chunks also gave two workgroups per CU but doubled the dependent memory
+// phases per edge and gained nothing.]
+#ifndef VSN_HF1_MINWAVES
+#define VSN_HF1_MINWAVES 4
+#endif
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf1(
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN), ((WPN > 1 && V <= 4 && !GEN) ? VSN_HF1_MINWAVES : 1)) void k_bwd_hf1(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
     float* __restrict__ g_t, float* __restrict__ g_geo, const float* __restrict__ vp, const float* __restrict__ pe,
     const float* __restrict__ g_f, float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_vh,
