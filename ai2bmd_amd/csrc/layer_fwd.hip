@@ -79,6 +79,18 @@ namespace vsn {
     }                                                                    \
   } while (0)
 
+// Lab builds (-DVSN_LAB_STAMPS): lane 0 of every wave of k_node_update stamps the 100 MHz real-time counter at its
+// phase boundaries into a buffer set with vsn_lab_set_stamps() (tools/lab/stamps_node_update.py prints the phases).
+#ifdef VSN_LAB_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define VSN_STAMP(k)                                                                                          \
+  do {                                                                                                        \
+    if (g_stamps && (threadIdx.x & 63) == 0)                                                                  \
+      g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define VSN_STAMP(k) do {} while (0)
+#endif
 // small batches (one protein per MD step): several waves per node
 static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
 static inline int node_grid(int N, int wpn) {
@@ -298,8 +310,10 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
                                                                            float* __restrict__ vec, NextNorm nn) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
+  VSN_STAMP(0);
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    VSN_STAMP(1);
     const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float Va[S][V];
 #pragma unroll
@@ -324,13 +338,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
 #pragma unroll
         for (int c = 0; c < V; ++c) Va[s][c] += vj[c] * s1[c] + ds * s2[c];
       }
+      VSN_STAMP(e < e0 + WPN ? 2 : (e < e0 + 2 * WPN ? 3 : 4));  // after the wave's 1st / 2nd / 3rd edge
     }
+    VSN_STAMP(5);
     if constexpr (WPN > 1 && S <= WPN && V <= 4) {
       // Small batches: instead of summing everything into wave 0 and letting it walk the S components alone,
       // reduce-SCATTER the partial sums (wave s receives the node total of component s) and let the S waves
       // update their component in parallel; only the channel-wise sum over s and the LayerNorm stay on wave 0.
       float tot[V], vdp[V];
       node_reduce_scatter<V, S, WPN>(Va, tot, smem, lane, sub);
+      VSN_STAMP(6);
 #pragma unroll
       for (int c = 0; c < V; ++c) vdp[c] = 0.f;
       if (sub < S) {
@@ -355,13 +372,16 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
           strow<V>(nn.vh + ((size_t)i * S + sub) * H, lane, vv);
         }
       }
+      VSN_STAMP(7);
       __syncthreads();  // everybody is done reading the partial sums
+      VSN_STAMP(8);
       if (sub > 0 && sub < S) {
         float* dst = smem + ((size_t)(sub - 1) * 64 + lane) * V;
 #pragma unroll
         for (int c = 0; c < V; ++c) dst[c] = vdp[c];
       }
       __syncthreads();
+      VSN_STAMP(9);
       if (sub == 0) {
         float vd[V], o2[V], o3[V], xv[V];
 #pragma unroll
@@ -377,7 +397,9 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
 #pragma unroll
         for (int c = 0; c < V; ++c) xv[c] += vd[c] * o2[c] + o3[c];
         strow<V>(x + (size_t)i * H, lane, xv);
+        VSN_STAMP(10);
         if (nn.xn) node_layernorm_store<V>(nn, i, H, lane, xv);
+        VSN_STAMP(11);
       }
     } else {
       node_reduce<V, S, WPN>(Va, smem, lane, sub);
@@ -561,3 +583,10 @@ int launch_fill(hipStream_t st, float* p, size_t n, float v) {
 }
 
 }  // namespace vsn
+
+#ifdef VSN_LAB_STAMPS
+extern "C" int vsn_lab_set_stamps(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vsn::g_stamps), &q, sizeof(q));
+}
+#endif
