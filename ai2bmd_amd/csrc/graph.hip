@@ -301,9 +301,17 @@ __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restri
   const float* g = geo + (size_t)e * 8;
   const float dC = g[2], ux = g[3], uy = g[4], uz = g[5], rinv = g[6];
   float gr = g_geo[(size_t)e * VSN_GEO_W + 8] * dC;
-  const float* gb = g_rbf + (size_t)e * Rp;
-  const float* db = drbf + (size_t)e * Rp;
-  for (int k = 0; k < Rp; ++k) gr += gb[k] * db[k];
+  // 16-byte loads (Rp is a multiple of 32: rows are 128-byte aligned); same summation order as a scalar loop
+  const float4* gb = reinterpret_cast<const float4*>(g_rbf + (size_t)e * Rp);
+  const float4* db = reinterpret_cast<const float4*>(drbf + (size_t)e * Rp);
+#pragma unroll 8
+  for (int k = 0; k < Rp / 4; ++k) {
+    const float4 a = gb[k], b = db[k];
+    gr += a.x * b.x;
+    gr += a.y * b.y;
+    gr += a.z * b.z;
+    gr += a.w * b.w;
+  }
   const float* gd0 = g_geo + (size_t)e * VSN_GEO_W;
   float gd[8];
 #pragma unroll
