@@ -55,3 +55,26 @@ def test_gemm_strided_views(eng):
     ref = A.cpu().double() @ Bt.cpu().double().T
     assert (C.cpu().double() - ref).abs().max().item() < 1e-4
     assert big_c[:, :128].abs().max().item() == 0 and big_c[:, 256:].abs().max().item() == 0
+
+
+def test_silu_prologue_extreme_inputs(eng):
+    """The activation on v_exp_f32 / v_rcp_f32 (csrc/common.h sigmoid_f) over the whole fp32 range: one-hot weights
+    turn the silu(A) product into silu(A) itself.  Saturation (|x| >> 88, where exp overflows / flushes), signed
+    zeros, denormals and +-inf limits must come out as torch's silu does, 2 ulp-ish everywhere else."""
+    vals = [0.0, -0.0, 1e-42, -1e-42, 1e-30, -1e-30, 1e-3, -1e-3, 0.5, -0.5, 1.0, -1.0, 5.0, -5.0, 20.0, -20.0,
+            80.0, -80.0, 87.0, -87.0, 88.5, -88.5, 89.0, -89.0, 100.0, -100.0, 1e4, -1e4, 3e38, -3e38]
+    K = 32
+    A = torch.zeros(64, K)
+    for i, v in enumerate(vals):
+        A[i, i % K] = v
+    A[40:, :] = torch.linspace(-30, 30, 24 * K).reshape(24, K)
+    Bt = torch.eye(K)  # C = silu(A) . I
+    Cd = torch.zeros(64, K, device="cuda:0")
+    eng.gemm(A.to("cuda:0"), Bt.to("cuda:0"), Cd, flags=2)
+    torch.cuda.synchronize()
+    got = Cd.cpu().double()
+    ref = torch.nn.functional.silu(A.double())
+    assert torch.isfinite(got).all(), "silu must saturate, not overflow"
+    err = (got - ref).abs()
+    tol = 4e-7 * ref.abs().clamp(min=1.0) + 1e-37
+    assert (err <= tol).all(), (err / tol).max().item()
