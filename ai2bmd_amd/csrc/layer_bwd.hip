@@ -92,7 +92,11 @@ static const bool g_bwd_env_read = [] {  // A/B switches, read once when the lib
   return true;
 }();
 // small batches (one protein per MD step): several waves per node
-static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
+static const int g_wpn_n = [] {  // several waves per node below this many nodes (env VSN_WPN_N, tuning aid)
+  const char* e = getenv("VSN_WPN_N");
+  return e ? atoi(e) : 4096;
+}();
+static inline int pick_wpn(int N) { return N < g_wpn_n ? VSN_WPN_SMALL : 1; }
 static inline int node_grid(int N, int wpn) {
   int g = wpn == 1 ? (N + 3) / 4 : N;
   if (g > 16384) g = 16384;

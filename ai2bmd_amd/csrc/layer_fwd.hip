@@ -12,6 +12,8 @@
 // Reference: ViSNet/model/utils.py:296-317 (NeighborEmbedding), :331-341
 // (EdgeEmbedding); visnet_block.py:237-312 (ViS_MP.forward/message/aggregate/
 // edge_update), :206-209 (vector_rejection); utils.py:165-249 (VecLayerNorm).
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -92,7 +94,11 @@ __device__ unsigned long long* g_stamps = nullptr;
 #define VSN_STAMP(k) do {} while (0)
 #endif
 // small batches (one protein per MD step): several waves per node
-static inline int pick_wpn(int N) { return N < 4096 ? VSN_WPN_SMALL : 1; }
+static const int g_wpn_n = [] {  // several waves per node below this many nodes (env VSN_WPN_N, tuning aid)
+  const char* e = getenv("VSN_WPN_N");
+  return e ? atoi(e) : 4096;
+}();
+static inline int pick_wpn(int N) { return N < g_wpn_n ? VSN_WPN_SMALL : 1; }
 static inline int node_grid(int N, int wpn) {
   int g = wpn == 1 ? (N + 3) / 4 : N;
   if (g > 16384) g = 16384;
