@@ -18,6 +18,7 @@
 
 #include "../../include/vsn.h"
 #include "kernels.h"
+#include "pgemm.h"
 
 using namespace vsn;
 
@@ -37,6 +38,9 @@ struct LayerW {
   float *Ws, *bs, *WsT;
   float *Wo, *bo, *WoT;
   float *ln_g, *ln_b, *vln_w;
+  // panel-GEMM copies (pgemm.h; hidden = 256 only, else null): MFMA-fragment order, K permuted by channel half for
+  // the fused products of fused.hip
+  float *WsTp, *We3Tp;
 };
 
 struct LayerBuf {
@@ -104,6 +108,7 @@ struct vsn_ctx {
   bool fuse_fwd = true, fuse_bwd_opt = true;
   bool fuse_head = true;  // fused node-local head kernel (head_fused.hip) on single-protein sizes
   bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
+  bool fuse_panel = true;  // fragment batches, hidden 256: gather kernels as prologues of panel GEMMs (fused.hip)
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -216,6 +221,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->fuse_head = value != 0;
   } else if (k == "split_rev") {
     c->split_rev = value != 0;
+  } else if (k == "fuse_panel") {
+    c->fuse_panel = value != 0;
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -246,6 +253,22 @@ std::vector<float> transposed(const std::vector<float>& w, int rows, int cols) {
   for (int r = 0; r < rows; ++r)
     for (int cidx = 0; cidx < cols; ++cidx) t[(size_t)cidx * rows + r] = w[(size_t)r * cols + cidx];
   return t;
+}
+// [Nc, K] weight matrix (row stride ld >= K) -> panel-GEMM fragment order (pgemm.h), logical column k placed at
+// kperm(k); padded for the kernels' read-ahead
+template <typename F>
+std::vector<float> pack_panel(const std::vector<float>& w, int Nc, int K, int ld, F kperm) {
+  std::vector<float> o((size_t)Nc * K + VSN_PGEMM_PAD_FLOATS, 0.f);
+  for (int n = 0; n < Nc; ++n)
+    for (int k = 0; k < K; ++k) o[pgemm_pack_index(n, kperm(k), K)] = w[(size_t)n * ld + k];
+  return o;
+}
+// K layout of the fused products: slice h (256 columns) = channels [128 h, 128 h + 128) of operand part 0, then of
+// part 1; a third part (columns 512..767) stays where it is
+inline int kperm_half(int k) {
+  if (k >= 512) return k;
+  const int part = k >> 8, c = k & 255;
+  return (c >> 7) * 256 + part * 128 + (c & 127);
 }
 std::vector<float> vcat(std::initializer_list<const std::vector<float>*> parts) {
   std::vector<float> o;
@@ -384,7 +407,15 @@ extern "C" int vsn_finalize(vsn_handle c) {
     o["We3T"] = P.add(transposed(We3, 3 * H, H));
     o["Ws"] = P.add(*Wsp);
     o["bs"] = P.add(*bsp);
-    o["WsT"] = P.add(transposed(*Wsp, 2 * H, H));
+    const std::vector<float> WsT = transposed(*Wsp, 2 * H, H);
+    o["WsT"] = P.add(WsT);
+    if (H == 256) {
+      // g_m = g_t . Ws: [H, 2H], K = [g_t1 | g_t2] cut by channel half; g_f += g_pe . We3: [H, 3H] ([H, 2H] for the
+      // layers without an edge update), K = [g_pk | g_pv | g_pf]
+      o["WsTp"] = P.add(pack_panel(WsT, H, 2 * H, 2 * H, kperm_half));
+      const int Ke = (last || l == 0) ? 2 * H : 3 * H;
+      o["We3Tp"] = P.add(pack_panel(transposed(We3, 3 * H, H), H, Ke, 3 * H, kperm_half));
+    }
     o["Wo"] = P.add(*Wop);
     o["bo"] = P.add(*bop);
     o["WoT"] = P.add(transposed(*Wop, 3 * H, H));
@@ -468,6 +499,8 @@ extern "C" int vsn_finalize(vsn_handle c) {
     w.Ws = B + o["Ws"];
     w.bs = B + o["bs"];
     w.WsT = B + o["WsT"];
+    w.WsTp = o.count("WsTp") ? B + o["WsTp"] : nullptr;
+    w.We3Tp = o.count("We3Tp") ? B + o["We3Tp"] : nullptr;
     w.Wo = B + o["Wo"];
     w.bo = B + o["bo"];
     w.WoT = B + o["WoT"];
@@ -858,6 +891,32 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // each end, every layer
     const bool streamless = (c->overlap & 2) && !c->debug && !l0 && bwd_streamless_ok(D);
     const bool side_bw = (c->overlap & 2) && !c->debug && !l0 && !streamless;
+    // fragment batches at hidden 256: the target-side vector-message and attention adjoints are prologues of the
+    // products they feed (fused.hip) - g_t and the attention part of g_pe never reach HBM
+    const bool panel = c->fuse_panel && !c->debug && !streamless && w.WsTp && bwd_batch_path(D) && panel_ok(D);
+    if (panel) {
+      if (side_bw) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, st));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        if (!last) RC(launch_bwd_side(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo, c->g_vec, b.tpre, c->g_vh));
+        else RC(launch_bwd_vecmsg_S(c->side, D, c->g_vec, b.tpre, c->g_vh));
+        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+      }
+      RC(launch_bwd_gm_fused(st, D, c->g_vec, b.vh, b.tpre, w.WsTp, c->g_m, c->g_geo));
+      RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));
+      // the edge-update adjoint (side stream) writes g_pe[:, 2H:3H], the third K-slice of the fused product
+      if (side_bw) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
+      RC(launch_bwd_gf_fused(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->sat_tmp, c->g_geo, w.We3Tp, c->g_f,
+                             (last || l0) ? 2 * H : 3 * H, last ? 0 : 1));
+      RC(launch_bwd_attn_QS(st, D, b.qkv, b.pe, c->g_m, c->sat_tmp, c->g_qkv));
+      GemmDesc gd[2];
+      int ng = 0;
+      if (!l0)
+        gd[ng++] = gemm_desc(c->g_vp, 5 * H, w.Wv5T, 5 * H, c->g_vh, H, nullptr, N * S, nullptr, H,
+                             last ? 3 * H : 5 * H, 1);
+      gd[ng++] = gemm_desc(c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0);
+      RC(launch_gemm_group(st, gd, ng));
+    } else {
     if (streamless) {
       RC(launch_bwd_hf1(st, D, c->g_vec, b.vh, b.tpre, c->g_t, c->g_geo, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_vh,
                         !last));
@@ -874,25 +933,26 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     }
     snapshot(c, st, "g_t", l, c->g_t, (size_t)Emax * 2 * H);
     Parts mparts{nullptr, 0, 0}, aparts{nullptr, 0, 0};
-    const bool split_rev = c->split_rev && !c->debug && N < 4096 && Emax < 32768 &&
+    GemmDesc gdr[2];
+    // g_A = g_o.Wo (N rows, tiny) rides along with g_m = g_t.Ws (E rows) in one grouped launch
+    gdr[0] = gemm_desc(c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0);
+    gdr[1] = gemm_desc(c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0);
+    // the K-slices below are a grouped-launch feature: decide with the predicate launch_gemm_group itself uses
+    const bool split_rev = c->split_rev && !c->debug && N < 4096 && Emax < 32768 && gemm_group_ok(gdr, 2) &&
                            (size_t)(2 * (size_t)Emax + 3 * (size_t)N) * H <= c->splitk_elems;
     {
-      // g_A = g_o.Wo (N rows, tiny) rides along with g_m = g_t.Ws (E rows) in one grouped launch
-      GemmDesc gd[2];
-      gd[0] = gemm_desc(c->g_t, 2 * H, w.WsT, 2 * H, c->g_m, H, nullptr, Emax, EP, H, 2 * H, 0);
-      gd[1] = gemm_desc(c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0);
       if (split_rev) {
         // single-protein sizes: these two long-K products give only ~1.75 64x64 tiles per CU (two waves per SIMD,
         // a latency-bound k-loop).  Cut K into slices of H (uniform 8-k-tile units, ~3.6 per CU) and let the
         // attention adjoint, which reads both results row by row anyway, add the slices up: no reduction launch.
-        gd[0].keep_parts = 2;
-        gd[0].part = c->splitk;
-        gd[1].keep_parts = 3;
-        gd[1].part = c->splitk + (size_t)2 * Emax * H;
-        mparts = Parts{gd[0].part, (size_t)Emax * H, 2};
-        aparts = Parts{gd[1].part, (size_t)N * H, 3};
+        gdr[0].keep_parts = 2;
+        gdr[0].part = c->splitk;
+        gdr[1].keep_parts = 3;
+        gdr[1].part = c->splitk + (size_t)2 * Emax * H;
+        mparts = Parts{gdr[0].part, (size_t)Emax * H, 2};
+        aparts = Parts{gdr[1].part, (size_t)N * H, 3};
       }
-      RC(launch_gemm_group(st, gd, 2));
+      RC(launch_gemm_group(st, gdr, 2));
     }
     if (streamless && !last)
       RC(launch_bwd_hf2(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts, b.vp,
@@ -915,6 +975,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
                              last ? 3 * H : 5 * H, 1);
       gd[ng++] = gemm_desc(c->g_qkv, 3 * H, w.WqkvT, 3 * H, c->g_xh, H, nullptr, N, nullptr, H, 3 * H, 0);
       RC(launch_gemm_group(st, gd, ng));
+    }
     }
     snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);

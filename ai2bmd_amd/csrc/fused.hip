@@ -1,0 +1,321 @@
+// Gather kernels fused INTO the MFMA products they feed (fragment batches, hidden = 256).
+//
+// The reverse pass of a ViS-MP layer (visnet_block.py:276-288 message, :290-295 edge update; adjoints in
+// layer_bwd.hip) alternates HBM-bound per-edge kernels with MFMA-bound dense products whose A operand those kernels
+// have just written: g_t[E,2H] (vector-message adjoint) -> g_m = g_t.Ws, and g_pe[E,3H] (attention / edge-update
+// adjoints) -> g_f += g_pe.We3.  On a fragment batch E is ~17 N, so each such operand is gigabytes per layer that
+// cross HBM twice, and while the gather kernel runs the matrix pipes idle (and vice versa).
+//
+// Here the per-edge kernel becomes the PROLOGUE of the panel GEMM (pgemm.h): a workgroup owns 64 consecutive edges,
+// computes their operand rows straight into the swizzled LDS panel, and multiplies them by the packed weights - the
+// operand never exists in HBM, and with two workgroups per CU the gathers of one run under the MFMAs of the other.
+// K is walked in slices of 256 panel columns; the slices are cut by CHANNEL HALF (slice h = the columns of every
+// operand part that belong to channels [128 h, 128 h + 128)), so that one pass over the edges produces exactly one
+// slice: a half-wave (32 lanes x 4 channels) per edge, 16-byte loads, per-head sums inside 32 / num_heads x ... lanes.
+// The packed weight matrices carry the matching K permutation (engine.hip: pack_panel).
+#include <cstdlib>
+
+#include "common.h"
+#include "kernels.h"
+#include "pgemm.h"
+
+namespace vsn {
+
+// like wave_multi_sum<8> (common.h) but over each 32-lane half of the wave: every lane ends with the total, over its
+// half, of component (lane & 7)
+__device__ __forceinline__ float half_multi_sum8(const float (&p)[8], int lane) {
+  const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+  float q[4], r[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float keep = b2 ? p[k + 4] : p[k], send = b2 ? p[k] : p[k + 4];
+    q[k] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float keep = b1 ? q[k + 2] : q[k], send = b1 ? q[k] : q[k + 2];
+    r[k] = keep + __shfl_xor(send, 2, 64);
+  }
+  const float keep = b0 ? r[1] : r[0], send = b0 ? r[0] : r[1];
+  float v = keep + __shfl_xor(send, 1, 64);
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 16, 64);
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// g_m[E,H] = g_t[E,2H] . Ws      with g_t produced on the fly (adjoint of the vector messages, target side;
+// same arithmetic as k_bwd_vecmsg_T):
+//   g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_e[s] ; g_t = [g_s1 act'(t1) | g_s2 act'(t2)]
+//   dE/dd_e[s] += sum_c g_vec_i[s][c] act(t2[c])                                  -> g_geo[e][0..7]
+// Panel slice h, columns: [0,128) = g_t1 channels 128 h .., [128,256) = g_t2 channels 128 h ..
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GEN>
+__global__ __launch_bounds__(256, 2) void k_bwd_gm_fused(Dims D, const float* __restrict__ g_vec,
+                                                         const float* __restrict__ vh,
+                                                         const float* __restrict__ tpre,
+                                                         const float* __restrict__ Bp, float* __restrict__ g_m,
+                                                         float* __restrict__ g_geo) {
+  typedef PgemmBwd<4> G;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int Meff = *D.ecount;
+  Meff = Meff < D.Emax ? Meff : D.Emax;
+  const int live = (Meff + 63) >> 6;
+  if ((int)blockIdx.x >= live) return;
+  const int p = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, live) : (int)blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+  const int l5 = lane & 31, hw = lane >> 5;
+  const int e0 = p * 64;
+  const int act = GEN ? D.act : VSN_ACT_SILU;
+  typename G::Acc acc;
+  G::zero(acc);
+  typename G::Ring ring;
+  G::prefetch(ring, Bp, 512, 0, wave, lane);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();  // every wave is done reading slice 0
+    const int c0 = 128 * h + 4 * l5;
+#pragma unroll 2
+    for (int t = 0; t < 8; ++t) {
+      const int r = wave * 16 + 2 * t + hw;  // panel row of this half-wave
+      const bool valid = e0 + r < Meff;
+      const int e = valid ? e0 + r : Meff - 1;
+      const int i = D.tgt[e], j = D.src[e];
+      const float* __restrict__ tp = tpre + (size_t)e * 512 + c0;
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(tp);
+      const f32x4 t2 = *reinterpret_cast<const f32x4*>(tp + 256);
+      const f32x4 dA = *reinterpret_cast<const f32x4*>(D.d + (size_t)e * 8);
+      const f32x4 dB = *reinterpret_cast<const f32x4*>(D.d + (size_t)e * 8 + 4);
+      const float geo_old = l5 < 8 ? g_geo[(size_t)e * VSN_GEO_W + l5] : 0.f;  // fetched with the other operands
+      const float ds[8] = {dA.x, dA.y, dA.z, dA.w, dB.x, dB.y, dB.z, dB.w};
+      const float* __restrict__ gvp = g_vec + (size_t)i * 8 * 256 + c0;
+      const float* __restrict__ vjp = vh + (size_t)j * 8 * 256 + c0;
+      f32x4 gv[8], vj[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        gv[s] = *reinterpret_cast<const f32x4*>(gvp + s * 256);
+        vj[s] = *reinterpret_cast<const f32x4*>(vjp + s * 256);
+      }
+      float d1[4], s2[4], d2[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        d1[c] = dact_f(act, t1[c]);
+        act_both(act, t2[c], s2[c], d2[c]);
+      }
+      f32x4 gs1 = {0.f, 0.f, 0.f, 0.f}, gs2 = {0.f, 0.f, 0.f, 0.f};
+      float pp[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        float pq = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gs1[c] += gv[s][c] * vj[s][c];
+          gs2[c] += gv[s][c] * ds[s];
+          pq += gv[s][c] * s2[c];
+        }
+        pp[s] = pq;
+      }
+      const float mine = half_multi_sum8(pp, lane);  // lane l5 < 8: sum over the half-wave of component l5
+      if (valid && l5 < 8) g_geo[(size_t)e * VSN_GEO_W + l5] = geo_old + mine;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        gs1[c] *= d1[c];
+        gs2[c] *= d2[c];
+      }
+      *reinterpret_cast<f32x4*>(smem + panel_at(r, l5)) = gs1;
+      *reinterpret_cast<f32x4*>(smem + panel_at(r, 32 + l5)) = gs2;
+    }
+    __syncthreads();
+    G::pin(ring);
+    G::slice(acc, ring, smem, Bp, 512, h, wave, lane);
+  }
+  G::template store<0>(acc, g_m, 256, e0, Meff, wave, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// g_f[E,H] (+)= g_pe[E,3H] . We3    with the attention part of g_pe produced on the fly (adjoint of attention /
+// scalar message, target side; same arithmetic as k_bwd_attn_T except that dE/dq is summed by k_bwd_attn_QS):
+//   gm = g_m_e + g_A_i (written back to g_m for the source-side sums) ; sat, a recomputed
+//   g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a act'(sat) C ; dE/dC += sum_h g_a act(sat)
+//   g_pk = g_sat q_i k_j act'(pk) ; g_pv = gm v_j a act'(pv) ; sat_tmp[e] = [g_sat | a]
+// Panel slice h (h = 0, 1), columns: [0,128) = g_pk channels 128 h .., [128,256) = g_pv channels 128 h ..;
+// slice 2 (layers with an edge update) = g_pf, copied by LDS-DMA from g_pe[:, 2H:3H] (written by the edge-update
+// adjoint).  K = 512 or 768.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GEN, int EPI>
+__global__ __launch_bounds__(256, 2) void k_bwd_gf_fused(Dims D, const float* __restrict__ qkv,
+                                                         const float* __restrict__ pe,
+                                                         const float* __restrict__ g_A, float* __restrict__ g_m,
+                                                         const float* __restrict__ g_pe,
+                                                         float* __restrict__ sat_tmp, float* __restrict__ g_geo,
+                                                         const float* __restrict__ Bp, float* __restrict__ g_f,
+                                                         int K) {
+  typedef PgemmBwd<4> G;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int Meff = *D.ecount;
+  Meff = Meff < D.Emax ? Meff : D.Emax;
+  const int live = (Meff + 63) >> 6;
+  if ((int)blockIdx.x >= live) return;
+  const int p = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, live) : (int)blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));
+  const int l5 = lane & 31, hw = lane >> 5;
+  const int e0 = p * 64;
+  const int act = GEN ? D.act : VSN_ACT_SILU, aact = GEN ? D.attn_act : VSN_ACT_SILU;
+  const int nh = D.nh;
+  const int lph = 64 / nh;  // lanes per head (4 channels per lane): 256 / nh / 4
+  typename G::Acc acc;
+  G::zero(acc);
+  typename G::Ring ring;
+  G::prefetch(ring, Bp, K, 0, wave, lane);
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+    const int c0 = 128 * h + 4 * l5;
+    const int head = (c0 * nh) >> 8;  // head of this lane's channels
+#pragma unroll 2
+    for (int t = 0; t < 8; ++t) {
+      const int r = wave * 16 + 2 * t + hw;
+      const bool valid = e0 + r < Meff;
+      const int e = valid ? e0 + r : Meff - 1;
+      const int i = D.tgt[e], j = D.src[e];
+      const float C = D.geo[(size_t)e * 8 + 1];
+      const float gC_old = l5 == 0 ? g_geo[(size_t)e * VSN_GEO_W + 8] : 0.f;
+      const f32x4 q = *reinterpret_cast<const f32x4*>(qkv + (size_t)i * 768 + c0);
+      const f32x4 gA = *reinterpret_cast<const f32x4*>(g_A + (size_t)i * 256 + c0);
+      const f32x4 k = *reinterpret_cast<const f32x4*>(qkv + (size_t)j * 768 + 256 + c0);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(qkv + (size_t)j * 768 + 512 + c0);
+      const f32x4 pk = *reinterpret_cast<const f32x4*>(pe + (size_t)e * 768 + c0);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pe + (size_t)e * 768 + 256 + c0);
+      f32x4 gm = *reinterpret_cast<const f32x4*>(g_m + (size_t)e * 256 + c0);
+      float dk[4], ddk[4], dv[4], ddv[4];
+      float part = 0.f, gpart = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        gm[c] += gA[c];
+        act_both(act, pk[c], dk[c], ddk[c]);
+        act_both(act, pv[c], dv[c], ddv[c]);
+        part += q[c] * k[c] * dk[c];
+        gpart += gm[c] * v[c] * dv[c];
+      }
+      if (valid) *reinterpret_cast<f32x4*>(g_m + (size_t)e * 256 + c0) = gm;
+      const float sat = group_sum(part, lph);
+      const float ga = group_sum(gpart, lph);
+      float ssat, dssat;
+      act_both(aact, sat, ssat, dssat);
+      const float a = ssat * C;
+      const float gsat = ga * dssat * C;
+      const bool head_lead = (l5 & (lph - 1)) == 0;
+      const float gC = half_sum(head_lead ? ga * ssat : 0.f);
+      if (valid && l5 == 0) g_geo[(size_t)e * VSN_GEO_W + 8] = gC_old + gC;
+      if (valid && head_lead) {
+        sat_tmp[(size_t)e * 2 * nh + head] = gsat;
+        sat_tmp[(size_t)e * 2 * nh + nh + head] = a;
+      }
+      f32x4 gpk, gpv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        gpk[c] = gsat * q[c] * k[c] * ddk[c];
+        gpv[c] = gm[c] * v[c] * a * ddv[c];
+      }
+      *reinterpret_cast<f32x4*>(smem + panel_at(r, l5)) = gpk;
+      *reinterpret_cast<f32x4*>(smem + panel_at(r, 32 + l5)) = gpv;
+    }
+    __syncthreads();
+    G::pin(ring);
+    G::slice(acc, ring, smem, Bp, K, h, wave, lane);
+  }
+  if (K > 512) {
+    __syncthreads();
+    panel_load_dma<64, 4>(smem, g_pe, 768, e0, Meff, 512, wave, lane);
+    __syncthreads();
+    G::pin(ring);
+    G::slice(acc, ring, smem, Bp, K, 2, wave, lane);
+  }
+  G::template store<EPI>(acc, g_f, 256, e0, Meff, wave, lane);
+}
+
+// ---- hosts ------------------------------------------------------------------------------------------------
+static int g_fuse_panel = 1;  // env VSN_FUSE_PANEL=0: never take the fused / panel kernels (A/B aid)
+static const bool g_fused_env = [] {
+  if (const char* e = getenv("VSN_FUSE_PANEL")) g_fuse_panel = atoi(e);
+  return true;
+}();
+
+bool panel_ok(const Dims& D) { return g_fuse_panel && D.H == 256 && D.S == 8 && D.nh >= 2 && D.nh <= 64; }
+
+template <typename K>
+static inline void panel_lds(K kern) {
+  static thread_local const void* done[16];
+  static thread_local int ndone = 0;
+  for (int i = 0; i < ndone; ++i)
+    if (done[i] == (const void*)kern) return;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  if (ndone < 16) done[ndone++] = (const void*)kern;
+}
+
+int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
+                        const float* WsTp, float* g_m, float* g_geo) {
+  if (D.Emax <= 0) return 0;
+  const bool gen = D.act != VSN_ACT_SILU;
+  const int grid = (D.Emax + 63) / 64;
+  if (gen) {
+    panel_lds(k_bwd_gm_fused<true>);
+    k_bwd_gm_fused<true><<<grid, 256, 65536, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
+  } else {
+    panel_lds(k_bwd_gm_fused<false>);
+    k_bwd_gm_fused<false><<<grid, 256, 65536, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
+  }
+  return 0;
+}
+
+int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A,
+                        float* g_m, const float* g_pe, float* sat_tmp, float* g_geo, const float* We3Tp, float* g_f,
+                        int K, int accumulate) {
+  if (D.Emax <= 0) return 0;
+  const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const int grid = (D.Emax + 63) / 64;
+#define VSN_GF(G_, E_)                                                                                              \
+  do {                                                                                                              \
+    panel_lds(k_bwd_gf_fused<G_, E_>);                                                                              \
+    k_bwd_gf_fused<G_, E_><<<grid, 256, 65536, st>>>(D, qkv, pe, g_A, g_m, g_pe, sat_tmp, g_geo, We3Tp, g_f, K);    \
+  } while (0)
+  if (gen) {
+    if (accumulate) VSN_GF(true, 2);
+    else VSN_GF(true, 0);
+  } else {
+    if (accumulate) VSN_GF(false, 2);
+    else VSN_GF(false, 0);
+  }
+#undef VSN_GF
+  return 0;
+}
+
+// plain panel products (fragment batches, hidden 256): fwd K == 256, bwd Nc == 256
+int launch_pgemm_fwd(hipStream_t st, const float* A, int lda, const float* Bp, float* C, int ldc, const float* bias,
+                     int M, const int* Mptr, int Nc, int accumulate) {
+  if (M <= 0) return 0;
+  if ((Nc & 127) || (lda & 3) || (ldc & 3)) return -22;
+  const int grid = (M + 63) / 64;
+#define VSN_PF(E_)                                                                                          \
+  do {                                                                                                      \
+    panel_lds(k_pgemm_fwd<2, 4, 8, E_>);                                                                    \
+    k_pgemm_fwd<2, 4, 8, E_><<<grid, 256, 65536, st>>>(A, lda, Bp, C, ldc, bias, M, Mptr, Nc, 1);           \
+  } while (0)
+  if (accumulate) {
+    if (bias) return -22;
+    VSN_PF(2);
+  } else if (bias) {
+    VSN_PF(1);
+  } else {
+    VSN_PF(0);
+  }
+#undef VSN_PF
+  return 0;
+}
+
+}  // namespace vsn

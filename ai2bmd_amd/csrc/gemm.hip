@@ -496,19 +496,31 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   return 0;
 }
 
+// would launch_gemm_group run these products as ONE grouped launch (the only form that can leave K-slices to a consumer)?
+bool gemm_group_ok(const GemmDesc* descs, int n) {
+  static const bool env_init = gemm_env_init();
+  (void)env_init;
+  if (!(n > 1 && n <= GemmGroup::MAXP)) return false;
+  for (int i = 0; i < n; ++i) {
+    const GemmDesc& d = descs[i];
+    if (d.M <= 0) continue;
+    if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) return false;
+    if (gemm_variant(d.M, d.Nc) == 0) return false;  // big enough to fill the chip alone
+    if (d.flags & 2) return false;                   // silu(A) has its own kernels
+  }
+  return true;
+}
+
 int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
   static const bool env_init = gemm_env_init();
   (void)env_init;
   // fall back to individual launches when the group would not use the 64x64 tiling anyway
-  bool groupable = n > 1 && n <= GemmGroup::MAXP;
+  const bool groupable = gemm_group_ok(descs, n);
   long long tiles = 0;
   for (int i = 0; i < n && groupable; ++i) {
     const GemmDesc& d = descs[i];
     if (d.M <= 0) continue;
-    if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) groupable = false;
     if (d.keep_parts > 1 && (!d.part || (d.K / 32) < d.keep_parts || (d.flags & 1) || d.bias)) return -22;
-    if (gemm_variant(d.M, d.Nc) == 0) groupable = false;  // big enough to fill the chip alone
-    if (d.flags & 2) groupable = false;                   // silu(A) has its own kernels
     tiles += (long long)((d.M + 63) / 64) * (d.Nc / 64);
   }
   if (!groupable) {

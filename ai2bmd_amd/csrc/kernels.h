@@ -115,6 +115,8 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
 // independent products in one launch (falls back to separate launches when not worthwhile)
 int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n);
+// the predicate launch_gemm_group uses: true = one grouped launch (callers that set keep_parts must check it)
+bool gemm_group_ok(const GemmDesc* descs, int n);
 
 int launch_graph(hipStream_t st, const GraphArgs& a);
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
@@ -165,6 +167,7 @@ struct Parts {
   int n;  // 0: not split, read the plain array
 };
 bool bwd_streamless_ok(const Dims& D);
+bool bwd_batch_path(const Dims& D);  // one wave per node (fragment batches), not the several-waves-per-node kernels
 int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre, float* g_t,
                    float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
                    float* g_vh, bool with_edge_update);
@@ -175,6 +178,21 @@ int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float*
 int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts = Parts{nullptr, 0, 0},
                     Parts g_A_parts = Parts{nullptr, 0, 0});
+int launch_bwd_attn_QS(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_m,
+                       const float* sat_tmp, float* g_qkv);
+
+// ---- fused.hip: gather kernels as prologues of panel GEMMs (fragment batches, hidden = 256) ----
+bool panel_ok(const Dims& D);
+// g_m = g_t . Ws with g_t (adjoint of the vector messages, target side) produced on the fly; WsTp = packed + K-permuted
+int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
+                        const float* WsTp, float* g_m, float* g_geo);
+// g_f (+)= g_pe . We3 with the attention part of g_pe produced on the fly (g_pf read from g_pe[:, 2H:3H] when K = 3H);
+// leaves g_m += g_A and sat_tmp = [g_sat | a] for launch_bwd_attn_QS
+int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A,
+                        float* g_m, const float* g_pe, float* sat_tmp, float* g_geo, const float* We3Tp, float* g_f,
+                        int K, int accumulate);
+int launch_pgemm_fwd(hipStream_t st, const float* A, int lda, const float* Bp, float* C, int ldc, const float* bias,
+                     int M, const int* Mptr, int Nc, int accumulate);
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh, const float* xn,
                          const float* rstd, const float* gamma, const float* wvec, int norm_type, int accumulate,
                          float* g_x, float* g_vec);

@@ -675,6 +675,37 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
   }
 }
 
+// ---- target side dE/dq alone: g_q_i = sum_{e -> i} g_sat_e k_j act(pk_e) ------------------------------
+// (fragment batches: the rest of the target-side attention adjoint is the prologue of the fused g_f product,
+//  fused.hip::k_bwd_gf_fused, which leaves g_sat in sat_tmp; a per-node sum cannot live in a per-edge-panel kernel)
+template <int V, int S, int WPN, bool GEN>
+__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_Q(
+    Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ sat_tmp,
+    float* __restrict__ g_qkv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int H = D.H;
+  const int nh = D.nh;
+  const int lph = 64 / nh;
+  VSN_NODE_LOOP(i, D.N, WPN) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
+    float gq[1][V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) gq[0][c] = 0.f;
+    for (int e = e0 + sub; e < e1; e += WPN) {
+      const int j = edge_cache_get(srcc, D.src, e, e0);
+      float k[V], pk[V];
+      ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
+      ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
+      const float gsat = sat_tmp[(size_t)e * 2 * nh + lane / lph];
+#pragma unroll
+      for (int c = 0; c < V; ++c) gq[0][c] += gsat * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+    }
+    node_reduce<V, 1, WPN>(gq, smem, lane, sub);
+    if (sub == 0) strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq[0]);
+  }
+}
+
 // ---- adjoint of LayerNorm + VecLayerNorm("none") ------------------------------------
 template <int V, int S, int WPN>
 __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __restrict__ g_xh, int ldg,
@@ -1064,6 +1095,7 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
 }
 // the streamless reverse chain of a layer at single-protein sizes (see k_bwd_hf1 / k_bwd_hf2); false = not applicable
 bool bwd_streamless_ok(const Dims& D) { return g_fuse_side >= 2 && pick_wpn(D.N) != 1 && D.N > 0; }
+bool bwd_batch_path(const Dims& D) { return pick_wpn(D.N) == 1 && D.N > 0; }
 int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre, float* g_t,
                    float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
                    float* g_vh, bool with_edge_update) {
@@ -1119,6 +1151,14 @@ int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts) {
   if (D.N <= 0) return 0;
   VSN_LAUNCH_ACT(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts);
+  VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
+  return 0;
+}
+// source side (dE/dk, dE/dv) + target side dE/dq, after fused.hip::k_bwd_gf_fused
+int launch_bwd_attn_QS(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_m,
+                       const float* sat_tmp, float* g_qkv) {
+  if (D.N <= 0) return 0;
+  VSN_LAUNCH_ACT(k_bwd_attn_Q, 1, D, qkv, pe, sat_tmp, g_qkv);
   VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
   return 0;
 }

@@ -75,6 +75,11 @@ class _MDBase:
         self.observers.append((fn, int(interval)))
 
     def run(self, steps):
+        # ASE 3.22 Dynamics.irun calls the attached observers once on the starting state (nsteps == 0) before the
+        # first step - the reference's MolDyn.run inherits that: initial frame + energy line, runaway guard included
+        if self.nsteps == 0:
+            for fn, _iv in self.observers:
+                fn()
         for _ in range(int(steps)):
             self.step()
             self.nsteps += 1
@@ -182,10 +187,15 @@ class LangevinHIP(_MDBase):
     generator keyed by (seed, step, atom), so trajectories are reproducible but differ from the
     torch-generator ones.  Restraints (tether / Hookean lists) are evaluated inside half2; self.F is model +
     restraints and self.E the model energy plus the restraint energy of the same evaluation (read lazily: the
-    restraint part is reduced on the device only when an observer asks)."""
+    restraint part is reduced on the device only when an observer asks).
+
+    In-place contract (`inplace_forces=True`, the default): half2 ADDS the restraint forces into the tensor
+    `force_fn` returned, so `force_fn` must hand back a buffer it rewrites on every call (the calculators of this
+    package do).  A `force_fn` that returns a cached / constant tensor, or keeps using its result, needs
+    `inplace_forces=False`: the integrator then works on its own copy (one extra copy kernel per step)."""
 
     def __init__(self, numbers, positions, force_fn, device, timestep_fs=1.0, temperature_K=300.0,
-                 friction_per_fs=0.001, seed=0, tether_k=0.0):
+                 friction_per_fs=0.001, seed=0, tether_k=0.0, inplace_forces=True):
         import ctypes as C
 
         from . import capi
@@ -198,6 +208,7 @@ class LangevinHIP(_MDBase):
         x0 = np.ascontiguousarray(positions, dtype=np.float32)
         self.x = torch.as_tensor(x0, device=device).contiguous()
         self.force_fn = force_fn
+        self.inplace_forces = bool(inplace_forces)
         self.tether_k = float(tether_k)
         self._x0 = x0.astype(np.float64)
         self.constraints = []
@@ -268,6 +279,8 @@ class LangevinHIP(_MDBase):
         if rc:
             raise RuntimeError(f"vsn_md_half1 failed ({rc})")
         self.E_model, F = self.force_fn(self.x)
+        if not self.inplace_forces:
+            F = F.clone()
         self.F = F if F.is_contiguous() else F.contiguous()
         rc = self._L.vsn_md_half2(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
                                   C.c_void_p(self.F.data_ptr()), st)
@@ -290,7 +303,8 @@ class LangevinHIP(_MDBase):
         return self.E_model + self._observe_device()[1]
 
     def kinetic_energy(self):
-        return self._observe_device()[0]
+        # a copy: _obs is rewritten by every later observe / E / kinetic_energy call
+        return self._observe_device()[0].clone()
 
     def observe(self):
         o = self._observe_device()

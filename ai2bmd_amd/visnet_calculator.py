@@ -192,20 +192,50 @@ def load_checkpoint(filepath):
     return m.hparams, m.state
 
 
+_ACT_NAMES = {"SiLU": "silu", "Swish": "swish", "ShiftedSoftplus": "ssp", "Tanh": "tanh", "Sigmoid": "sigmoid"}
+
+
+def _act_name(layer_act):
+    """activation name of a (possibly TorchScript-compiled) activation module"""
+    cls = getattr(layer_act, "original_name", None) or type(layer_act).__name__
+    if cls not in _ACT_NAMES:
+        raise TypeError(f"hparams_of_module: unknown activation module {cls}")
+    return _ACT_NAMES[cls]
+
+
 def hparams_of_module(model) -> dict:
     """Hyper-parameters of a torch ViSNet module built by the reference's create_model (visnet.py:14-70), read off
     the attributes ViSNetBlock keeps (visnet_block.py:40-55) - so that a reference module can be handed to
-    `ViSNetModel(model, device)` exactly where the reference constructs its own."""
+    `ViSNetModel(model, device)` exactly where the reference constructs its own.  The reference's load_model returns
+    `torch.jit.script(model)` (visnet.py:92): a scripted module keeps the sub-module tree, the state_dict and
+    `original_name`, but not every plain Python attribute, so sizes fall back to the state_dict shapes and the
+    remaining scalars must be readable (TorchScript keeps int/float/str attributes that the scripted code uses)."""
     rep = model.representation_model
-    layer = rep.vis_mp_layers[0]
-    names = {"SiLU": "silu", "Swish": "swish", "ShiftedSoftplus": "ssp", "Tanh": "tanh", "Sigmoid": "sigmoid"}
+    sd = model.state_dict()
+    layers = rep.vis_mp_layers
+    layer = layers[0]
+
+    def attr(name, default=None):
+        v = getattr(rep, name, default)
+        if v is None:
+            raise TypeError(f"hparams_of_module: the module does not expose `{name}` (a scripted module that dropped "
+                            "it): pass the checkpoint through load_model() instead")
+        return v
+
+    H = int(sd["representation_model.embedding.weight"].shape[1])
+    L = len(layers)
+    R = int(sd["representation_model.neighbor_embedding.distance_proj.weight"].shape[1])
+    max_z = int(sd["representation_model.embedding.weight"].shape[0])
+    act = getattr(rep, "activation", None)
+    attn = getattr(rep, "attn_activation", None)
     prior = getattr(model, "prior_model", None)
     return dict(
         model="ViSNetBlock", output_model="Scalar", reduce_op=getattr(model, "reduce_op", "add"),
-        embedding_dimension=int(rep.hidden_channels), num_layers=int(rep.num_layers), num_rbf=int(rep.num_rbf),
-        num_heads=int(rep.num_heads), lmax=int(rep.lmax), max_z=int(rep.max_z), cutoff=float(rep.cutoff),
-        max_num_neighbors=int(rep.max_num_neighbors), vecnorm_type=rep.vecnorm_type, rbf_type=rep.rbf_type,
-        activation=names[type(layer.act).__name__], attn_activation=names[type(layer.attn_activation).__name__],
+        embedding_dimension=H, num_layers=L, num_rbf=R,
+        num_heads=int(attr("num_heads")), lmax=int(attr("lmax")), max_z=max_z, cutoff=float(attr("cutoff")),
+        max_num_neighbors=int(attr("max_num_neighbors")), vecnorm_type=attr("vecnorm_type"), rbf_type=attr("rbf_type"),
+        activation=act if isinstance(act, str) else _act_name(layer.act),
+        attn_activation=attn if isinstance(attn, str) else _act_name(layer.attn_activation),
         prior_model="Atomref" if prior is not None else None,
     )
 
@@ -220,6 +250,9 @@ class ViSNetModel:
         """`ViSNetModel(model, device=...)` like the reference (:35): `model` is what `load_model` returned, or a torch
         ViSNet module built by the reference's create_model.  The three-argument form `(hparams, state_dict, device)`
         builds one from in-memory weights."""
+        if isinstance(state_dict, (str, torch.device)):
+            # the reference's positional form ViSNetModel(model, "cuda:0") (visnet_calculator.py:35)
+            device, state_dict = state_dict, None
         if state_dict is not None:
             hparams, sd = model, state_dict
         elif isinstance(model, LoadedViSNet):
