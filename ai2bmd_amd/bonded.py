@@ -133,9 +133,12 @@ class ShardedFragmentForces:
     product wiring is `ShardedFragmentForces.for_engine(...)`.
     """
 
-    def __init__(self, plan: FragmentPlan, rank: int, world: int, device, group=None):
+    def __init__(self, plan: FragmentPlan, rank: int, world: int, device, group=None, balance: str = "atoms"):
+        """balance: "atoms" = the reference's partition rule (device_strategy.py:84-127), "cost" = the same rule on
+        the fragments' edge counts (see device_strategy.device_ranges)."""
         self.plan, self.rank, self.world, self.device, self.group = plan, rank, world, device, group
-        self.ranges = device_ranges(plan.start, plan.end, world)
+        self.balance = balance
+        self.ranges = device_ranges(plan.start, plan.end, world, balance=balance)
         self.f0, self.f1 = self.ranges[rank]
         starts = np.append(plan.start, plan.end[-1])
         self.atom_lo = [int(starts[a]) for a, _ in self.ranges]
@@ -201,12 +204,12 @@ class ShardedFragmentForces:
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
     def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None,
-                   force_collective=False):
+                   force_collective=False, balance: str = "atoms"):
         """hydrogen: optional ai2bmd_amd.hydrogen.HydrogenPlan - relax the cap hydrogens every call like
         DistanceFragment.get_fragments (distancefrag.py:76-82).  The relaxation couples all dipeptides, so with
         it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard."""
         dev = engine.device
-        self = cls(plan, rank, world, dev, group)
+        self = cls(plan, rank, world, dev, group, balance=balance)
         self.force_collective = bool(force_collective)
         L = capi.lib()
         lo, hi = self.atom_lo[rank], self.atom_hi[rank]

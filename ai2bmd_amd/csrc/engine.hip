@@ -81,6 +81,15 @@ struct vsn_ctx {
   bool debug = false;
   bool profile = false;
   double prof[4][4] = {{0}};  // per GEMM kernel (128x128, 64x64, 128x32, grouped 64x64): launches, ms, flops, bytes
+  // profile mode, scatter path: brackets around the forward edge-attention (0) and node-update (1) launches:
+  // {launches, ms, algorithmic bytes, 0}
+  double sprof[2][4] = {{0}};
+  struct SRec {
+    hipEvent_t a, b;
+    int kind, N;
+    bool with_update, fused_norm;
+  };
+  std::vector<SRec> srecs;
   double prof_empty_ms = 0;   // profile mode: total time of EMPTY event brackets (the cost an event pair adds) ...
   double prof_empty_n = 0;    // ... and how many were measured
   int64_t max_chunk_edges = 1048576;  // ~84 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s)
@@ -228,6 +237,7 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
   } else if (k == "profile") {
     c->profile = value != 0;
     memset(c->prof, 0, sizeof(c->prof));
+    memset(c->sprof, 0, sizeof(c->sprof));
     c->prof_empty_ms = c->prof_empty_n = 0;
   } else {
     return fail(c, -22, "unknown option " + k);
@@ -672,6 +682,29 @@ static void snapshot(vsn_ctx* c, hipStream_t st, const char* name, int layer, co
   hipMemcpyAsync(v[layer], p, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
 }
 
+// profile mode: HIP events around one scatter-path launch (same stream), resolved after the chunk
+struct ScatterBracket {
+  vsn_ctx* c;
+  hipStream_t st;
+  bool on;
+  ScatterBracket(vsn_ctx* c_, hipStream_t st_, int kind, int N, bool with_update, bool fused_norm)
+      : c(c_), st(st_), on(c_->profile) {
+    if (!on) return;
+    vsn_ctx::SRec r;
+    r.kind = kind;
+    r.N = N;
+    r.with_update = with_update;
+    r.fused_norm = fused_norm;
+    hipEventCreate(&r.a);
+    hipEventCreate(&r.b);
+    hipEventRecord(r.a, st);
+    c->srecs.push_back(r);
+  }
+  ~ScatterBracket() {
+    if (on) hipEventRecord(c->srecs.back().b, st);
+  }
+};
+
 // ---------------------------------------------------------------------------------
 // one chunk: forward + reverse
 // ---------------------------------------------------------------------------------
@@ -822,8 +855,11 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     }
     // single-protein sizes: the edge update rides in the attention launch (horizontal fusion)
     const bool fused_eu = c->fuse_fwd && !side_eu && !c->debug && !last && !l0 && N < 4096;
-    if (fused_eu) RC(launch_edge_attn_update(st, D, b.qkv, b.pe, c->m, c->A, b.vp, c->f));
-    else RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
+    {
+      ScatterBracket sb(c, st, 0, N, fused_eu, false);
+      if (fused_eu) RC(launch_edge_attn_update(st, D, b.qkv, b.pe, c->m, c->A, b.vp, c->f));
+      else RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
+    }
     snapshot(c, st, "m", l, c->m, (size_t)Emax * H);
     snapshot(c, st, "A", l, c->A, (size_t)N * H);
     {
@@ -844,6 +880,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
           nn = NextNorm{c->on_g, c->on_b, c->vo_w, c->xn_o, c->rstd_o, c->hb.cat0, c->vo, 2 * H};
         }
       }
+      ScatterBracket sb(c, st, 1, N, false, fuse_norm);
       RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec, nn));
     }
     if (side_eu) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -1072,6 +1109,24 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
         }
       }
       for (int k = 0; k < 16; ++k) hipEventDestroy(empty[k]);
+      for (auto& r : c->srecs) {
+        // algorithmic (compulsory) HBM bytes of the launch: every array it touches once
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+        const double H = c->H, S = c->S, n = r.N, e = E;
+        double fl;
+        if (r.kind == 0)  // edge attention (+ edge update): pe[dk|dv], C, src | qkv | m, A  (+ pe[f], f r/w, d, vp[wt|ws])
+          fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1) + (r.with_update ? e * (3 * H + 8) + n * S * 2 * H : 0.0);
+        else  // node update: tpre, d, src | vh, vp[vec1..3], o, x r/w, vec r/w (+ next layer's xn, xh, rstd, vh)
+          fl = e * (2 * H + 8 + 1) + n * (S * H * (1 + 3 + 2) + 3 * H + 2 * H + 1) +
+               (r.fused_norm ? n * (2 * H + 1 + S * H) : 0.0);
+        c->sprof[r.kind][0] += 1;
+        c->sprof[r.kind][1] += ms;
+        c->sprof[r.kind][2] += 4.0 * fl;
+      }
+      c->srecs.clear();
       for (auto& r : gp.recs) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
@@ -1102,6 +1157,13 @@ extern "C" int vsn_profile_read(vsn_handle c, double* out16) {
   if (!c || !out16) return -22;
   for (int v = 0; v < 4; ++v)
     for (int k = 0; k < 4; ++k) out16[v * 4 + k] = c->prof[v][k];
+  return 0;
+}
+
+extern "C" int vsn_profile_read_scatter(vsn_handle c, double* out8) {
+  if (!c || !out8) return -22;
+  for (int v = 0; v < 2; ++v)
+    for (int k = 0; k < 4; ++k) out8[v * 4 + k] = c->sprof[v][k];
   return 0;
 }
 

@@ -35,9 +35,28 @@ def work_partitions(start, end, n_devices: int, chunk_atoms: int = DEFAULT_CHUNK
     return [tuple(int(v) for v in out[3 * i:3 * i + 3]) for i in range(n)]
 
 
-def device_ranges(start, end, n_devices: int):
+def fragment_cost(start, end, max_num_neighbors: int = 32):
+    """Work of one fragment ~ its edge count: n * min(n, max_num_neighbors + 1) (dipeptides are smaller than the
+    cutoff sphere, so nearly every pair is an edge; self loops included) - the per-edge linears and gathers are
+    ~ 80 % of an evaluation, SURVEY.md 8e."""
+    n = np.asarray(end, dtype=np.int64) - np.asarray(start, dtype=np.int64)
+    return n * np.minimum(n, int(max_num_neighbors) + 1)
+
+
+def device_ranges(start, end, n_devices: int, balance: str = "atoms", max_num_neighbors: int = 32):
     """Per-device contiguous fragment range [(f0, f1)] (chunks merged) - what one
-    rank of the multi-GPU calculator owns."""
+    rank of the multi-GPU calculator owns.
+
+    balance = "atoms": the reference's rule (device_strategy.py:84-127, blocks of equal ATOM count);
+    balance = "cost":  the same cutting rule applied to the cumulative EDGE count (n_f * min(n_f, max_nb + 1))
+    instead of the cumulative atom count - the step of a rank follows its edges, and the step of the job is the
+    slowest rank's (a 36-atom TRP dipeptide costs 9x a 12-atom ACE-NME, not 3x)."""
+    if balance == "cost":
+        cost = fragment_cost(start, end, max_num_neighbors)
+        cum = np.cumsum(cost)
+        start, end = cum - cost, cum
+    elif balance != "atoms":
+        raise ValueError(f"device_ranges: unknown balance {balance!r}")
     parts = work_partitions(start, end, n_devices, chunk_atoms=1 << 40)
     rng = [(0, 0)] * n_devices
     seen = {}

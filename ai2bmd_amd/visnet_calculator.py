@@ -110,6 +110,14 @@ class ViSNetEngine:
         return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], flops=out[4 * v + 2], bytes=out[4 * v + 3])
                 for v in range(4)}
 
+    def profile_read_scatter(self):
+        """-> {kernel: dict(launches, ms, bytes)} of the bracketed scatter-path launches (forward edge attention and
+        vector-message aggregation + node update), accumulated since set_option('profile', 1)."""
+        out = (C.c_double * 8)()
+        self._check(self._L.vsn_profile_read_scatter(self._h, out))
+        names = ("k_edge_attn", "k_node_update")
+        return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], bytes=out[4 * v + 2]) for v in range(2)}
+
     def profile_bracket_ms(self) -> float:
         """Average cost of an empty HIP-event bracket measured in the profiled calls (subtract it per launch)."""
         return float(self._L.vsn_profile_bracket_ms(self._h))

@@ -100,6 +100,12 @@ int vsn_forces(vsn_handle h, const int64_t* dev_z, const float* dev_pos, const i
  * out[4v..4v+3] = {launches, total ms, total algorithmic flops, total algorithmic bytes}
  * accumulated since the option was set. */
 int vsn_profile_read(vsn_handle h, double* out16);
+/* Same profile mode, the scatter path: the forward edge-attention launch (k_edge_attn / k_edge_attn_update, v = 0) and
+ * the vector-message aggregation + node update (k_node_update, v = 1) of every layer are bracketed too;
+ * out[4v..4v+3] = {launches, total ms, total ALGORITHMIC HBM bytes (every array the launch touches, once), 0}.
+ * (replaces reading torch_scatter / MessagePassing.propagate time off a profiler in the reference,
+ *  ViSNet/model/visnet_block.py:276-312) */
+int vsn_profile_read_scatter(vsn_handle h, double* out8);
 /* Average time (ms) between the two events of an EMPTY bracket on the launch stream, measured in the same profiled
  * calls (8 per chunk): what the bracket itself adds to every per-launch figure above.  0 when nothing was measured. */
 double vsn_profile_bracket_ms(vsn_handle h);

@@ -4,6 +4,7 @@ ABD B=93 N=1850) at the reference's DEFAULT hyper-parameters (H=256, L=9) with b
 evaluated by the REFERENCE's own ViSNet source (/root/reference/src/ViSNet/model through oracle/shims).
 
     python -m oracle.make_protein_golden          (build container only)
+    python -m oracle.make_protein_golden --small  (Chignolin at H=128, L=6: the small variant of SURVEY 8d)
 
 Two geometries per protein, both from tests/golden/protein_<name>.npz through our fragment plan (which is pinned
 row for row on the reference's own DistanceFragment, tests/golden/fragref_chig.npz):
@@ -51,10 +52,14 @@ def max_degree(pos, start, end, cutoff):
 
 
 def main():
-    hp = default_hparams()
+    # `--small`: the SURVEY 8(d) small variant (H = 128, L = 6, "since the trained values are unknown") on Chignolin
+    # only -> tests/golden/visnet_prot_chig_h128l6.npz (bench.py's `secondary` small-variant line is guarded by it)
+    small = "--small" in sys.argv
+    hp = default_hparams(embedding_dimension=128, num_layers=6) if small else default_hparams()
+    suffix = "_h128l6" if small else ""
     sd = make_state_dict(hp, seed=WEIGHT_SEED)
     tables = load_tables(os.path.join(GOLD, "amber_tables.npz"))
-    for name in PROTEINS:
+    for name in (("chig",) if small else PROTEINS):
         z = np.load(os.path.join(GOLD, f"protein_{name}.npz"))
         p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
                          positions=z["positions"].astype(np.float64))
@@ -77,7 +82,7 @@ def main():
             print(f"{name}/{tag}: B={len(plan.start)} N={len(plan.z)} deg_max={out[f'max_degree_{tag}']} "
                   f"|F|max={np.abs(F64).max():.3f} fp32-vs-fp64 dE={np.abs(E32 - E64).max():.2e} "
                   f"dF={np.abs(F32 - F64).max():.2e}", flush=True)
-        np.savez_compressed(os.path.join(GOLD, f"visnet_prot_{name}.npz"), **out)
+        np.savez_compressed(os.path.join(GOLD, f"visnet_prot_{name}{suffix}.npz"), **out)
 
 
 if __name__ == "__main__":

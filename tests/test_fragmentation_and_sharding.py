@@ -189,3 +189,26 @@ def test_amber_ordered_plan_is_row_identical_to_the_reference(name):
     o = np.argsort(ref["select_index"])
     assert np.array_equal(plan.select_index, ref["select_index"][o])
     assert np.array_equal(plan.origin_index, ref["origin_index"][o])
+
+
+def test_edge_balanced_device_ranges_cover_and_balance():
+    """device_ranges(balance="cost"): the reference's cutting rule on cumulative edge counts - contiguous, covering,
+    and never worse balanced (max edge cost over ranks) than the atom rule on the example proteins."""
+    from ai2bmd_amd.device_strategy import device_ranges, fragment_cost
+    from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan
+
+    for name in ("chig", "trpcage", "ww", "abd"):
+        d = np.load(os.path.join(GOLDEN, f"protein_{name}.npz"))
+        plan = build_plan(ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"],
+                                       d["positions"].astype(np.float64)))
+        cost = fragment_cost(plan.start, plan.end)
+        for w in (1, 2, 4, 8):
+            worst = {}
+            for rule in ("atoms", "cost"):
+                r = device_ranges(plan.start, plan.end, w, balance=rule)
+                assert r[0][0] == 0 and r[-1][1] == len(plan.start)
+                assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+                worst[rule] = max(int(cost[a:b].sum()) for a, b in r)
+            assert worst["cost"] <= worst["atoms"] * 1.02, (name, w, worst)
+    with pytest.raises(ValueError):
+        device_ranges(plan.start, plan.end, 2, balance="nope")

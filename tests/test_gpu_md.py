@@ -152,7 +152,8 @@ def test_observers_preequilibration_and_runaway_guard(lib_built):
     md.attach(lambda: snaps.append(md.x.clone()), interval=10)      # trajectory frames stay in HBM
     md.attach(lambda: md.printenergy(quiet=True), interval=5)
     md.run(30)
-    assert seen == [5, 10, 15, 20, 25, 30] and len(snaps) == 3 and snaps[0].is_cuda
+    # ASE 3.22 Dynamics.irun: every observer also sees the starting state (nsteps == 0) once
+    assert seen == [0, 5, 10, 15, 20, 25, 30] and len(snaps) == 4 and snaps[0].is_cuda
     epot, ekin, temp = md.observe()
     assert abs(temp - 2.0 * ekin / (3 * n * KB)) < 1e-3 * temp and abs(ekin - float(0.5 * (md.m * md.v ** 2).sum())) < 1e-3
     x_before = md.x.clone()

@@ -97,9 +97,10 @@ def test_sharded_step_matches_reference_protein_forces(model, name):
     E, F = ShardedFragmentForces.for_engine(model.engine, plan, hydrogen=hplan).step(x)
     torch.cuda.synchronize()
     Fg, Eg = g["Fprot64_relaxed"], float(g["Eprot64_relaxed"])
-    assert np.abs(F.cpu().numpy() - Fg).max() <= 1e-3 * max(1.0, np.abs(Fg).max())
-    assert np.abs(F.cpu().numpy() - Fg).mean() <= 1e-4 * max(1.0, np.abs(Fg).max())
-    assert abs(float(E) - Eg) <= 1e-3 * max(1.0, abs(Eg))
+    # SURVEY 8c contract for the relaxed path as well (measured on MI355X: 2e-6; a 50x regression would fail)
+    assert np.abs(F.cpu().numpy() - Fg).max() <= 1e-4 * max(1.0, np.abs(Fg).max())
+    assert np.abs(F.cpu().numpy() - Fg).mean() <= 1e-5 * max(1.0, np.abs(Fg).max())
+    assert abs(float(E) - Eg) <= 1e-4 * max(1.0, abs(Eg))
 
 
 def test_two_rank_shards_reassemble_protein_forces(model):
@@ -155,7 +156,7 @@ def test_dl_bonded_calculator_reference_constructor_and_call(model, tmp_path):
     E, F = calc(prot)
     Fg, Eg = g["Fprot64_relaxed"], float(g["Eprot64_relaxed"])
     assert F.shape == Fg.shape and F.dtype == np.float32
-    assert np.abs(F - Fg).max() <= 1e-3 * max(1.0, np.abs(Fg).max()) and abs(float(E) - Eg) <= 1e-3 * max(1.0, abs(Eg))
+    assert np.abs(F - Fg).max() <= 1e-4 * max(1.0, np.abs(Fg).max()) and abs(float(E) - Eg) <= 1e-4 * max(1.0, abs(Eg))
     # the relaxed fragment positions themselves: cap hydrogens within 2e-4 A of the reference optimiser's
     fd = calc.fragment_method.get_fragments(prot)
     assert np.abs(fd.pos - g["pos_relaxed"]).max() < 5e-4

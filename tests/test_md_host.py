@@ -36,8 +36,9 @@ def test_langevin_observers_and_preequilibration_schedule():
     stages = []
     md.attach(lambda: stages.append((md.nsteps, len(md.constraints), md.constraints[0].k if md.constraints else 0.0)), 1)
     md.pre_equilibrate(list(range(n)), preeq_steps=2)
-    assert [s[0] for s in stages] == list(range(1, 11)) and all(s[1] == n for s in stages)
-    ks = [round(s[2] / KCALMOL2EV, 6) for s in stages[::2]]
+    # ASE 3.22 Dynamics.irun: the observers also see the starting state once (nsteps == 0), then every step
+    assert [s[0] for s in stages] == list(range(0, 11)) and all(s[1] == n for s in stages)
+    ks = [round(s[2] / KCALMOL2EV, 6) for s in stages[1::2]]
     assert ks == [10, 5, 1, 0.5, 0.1] and md.constraints == []      # simulator.py:143
     epot, ekin, temp = md.observe()
     assert abs(temp - 2 * ekin / (3 * n * KB)) < 1e-9

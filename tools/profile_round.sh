@@ -32,18 +32,32 @@ for W in chig batch; do
 done
 # per-launch HBM bytes of the dominant GEMM kernels (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes; FETCH doubled on gfx950),
 # read back by bench.py as roofline.traffic
-python - "$OUT" <<'PY'
+python - "$OUT" "$R" <<'PY'
 import csv, json, sys
-out = sys.argv[1]
+out, root = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+from ai2bmd_amd.build import _digest
 res = {}
-for wl, tag, pat, key in (("chig_md", "chig", "k_gemm_group", "k_gemm_group"), ("frag_batch", "batch", "k_gemm<128; 128", "k_gemm<128,128>")):
-    for r in csv.DictReader(open(f"{out}/{tag}_pmc.csv")):
-        if pat in r["kernel"] and r.get("hbm_MB") not in (None, "", "nan"):
-            res[wl] = {key: float(r["hbm_MB"]) * 1e6}
-            break
+want = {
+    "chig_md": ("chig", [("k_gemm_group", "k_gemm_group"), ("k_node_update<", "k_node_update"),
+                         ("k_edge_attn", "k_edge_attn"), ("k_bwd_hf1", "k_bwd_hf1")]),
+    "frag_batch": ("batch", [("k_gemm<128; 128", "k_gemm<128,128>"), ("k_node_update<", "k_node_update"),
+                             ("k_edge_attn<", "k_edge_attn"), ("k_bwd_gm_fused", "k_bwd_gm_fused"),
+                             ("k_bwd_gf_fused", "k_bwd_gf_fused")]),
+}
+for wl, (tag, pats) in want.items():
+    rows = list(csv.DictReader(open(f"{out}/{tag}_pmc.csv")))
+    for pat, key in pats:
+        for r in rows:
+            if pat in r["kernel"] and r.get("hbm_MB") not in (None, "", "nan"):
+                res.setdefault(wl, {})[key] = float(r["hbm_MB"]) * 1e6
+                break
+res["build_digest"] = _digest()
 res["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB*1024) averaged over all launches of the kernel in "
                 "the <tag>_pmc.csv of this directory (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
-                "tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section)")
+                "tools/profile_round.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section); build_digest = "
+                "ai2bmd_amd.build._digest() of the kernel sources measured: bench.py reports these figures only while "
+                "the library it runs is that build")
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(res)
 PY
