@@ -92,7 +92,8 @@ struct vsn_ctx {
   std::vector<SRec> srecs;
   double prof_empty_ms = 0;   // profile mode: total time of EMPTY event brackets (the cost an event pair adds) ...
   double prof_empty_n = 0;    // ... and how many were measured
-  int64_t max_chunk_edges = 1048576;  // ~84 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s)
+  int64_t max_chunk_edges = 1572864;  // ~126 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s; round 3:
+                                      // a 4096-fragment batch, 1.37 M edges, as ONE chunk instead of two: +0.9 %)
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
   float *geo, *d, *rbf, *drbf;
@@ -271,6 +272,16 @@ std::vector<float> pack_panel(const std::vector<float>& w, int Nc, int K, int ld
   std::vector<float> o((size_t)Nc * K + VSN_PGEMM_PAD_FLOATS, 0.f);
   for (int n = 0; n < Nc; ++n)
     for (int k = 0; k < K; ++k) o[pgemm_pack_index(n, kperm(k), K)] = w[(size_t)n * ld + k];
+  return o;
+}
+// [Nc, K] weight matrix -> fragment order of the fused head's 16x16x4 MFMA products (head_fused.hip::lds_gemm):
+// block (cb = n / 16, kg = k / 16) = 64 lanes x 4 floats, lane = (n % 16) + 16 * ((k % 16) / 4), component k % 4
+std::vector<float> pack_head(const std::vector<float>& w, int Nc, int K) {
+  std::vector<float> o((size_t)Nc * K + 16 * 256, 0.f);  // + read-ahead of the weight ring
+  const int KG = K / 16;
+  for (int n = 0; n < Nc; ++n)
+    for (int k = 0; k < K; ++k)
+      o[(((size_t)(n >> 4) * KG + (k >> 4)) * 64 + (n & 15) + 16 * ((k & 15) >> 2)) * 4 + (k & 3)] = w[(size_t)n * K + k];
   return o;
 }
 // K layout of the fused products: slice h (256 columns) = channels [128 h, 128 h + 128) of operand part 0, then of
@@ -463,6 +474,17 @@ extern "C" int vsn_finalize(vsn_handle c) {
     std::vector<float> wb1(Wb1->begin(), Wb1->begin() + h2);
     off["wb1"] = P.add(wb1);
   }
+  const bool head_packed = (H % 64) == 0 && H <= 256;
+  if (head_packed) {
+    off["Wa0p"] = P.add(pack_head(*Wa0, H, 2 * H));
+    off["Wb0p"] = P.add(pack_head(*Wb0, H, H));
+    off["W11p"] = P.add(pack_head(*W11, h2, h2));
+    off["Wa1p"] = P.add(pack_head(*Wa1, h2, H));
+    off["Wa1Tp"] = P.add(pack_head(transposed(*Wa1, h2, H), H, h2));
+    off["W11Tp"] = P.add(pack_head(transposed(*W11, h2, h2), h2, h2));
+    off["Wb0Tp"] = P.add(pack_head(transposed(*Wb0, H, H), H, H));
+    off["Wa0Tp"] = P.add(pack_head(transposed(*Wa0, H, 2 * H), 2 * H, H));
+  }
   bool has_ar = c->hp.has_atomref != 0;
   if (has_ar) {
     // the Atomref table takes its size from prior_args["max_z"] (ViSNet/model/priors.py:62-77), not from the
@@ -533,6 +555,14 @@ extern "C" int vsn_finalize(vsn_handle c) {
   hw.ba1 = B + off["ba1"];
   hw.Wa1T = B + off["Wa1T"];
   hw.wb1 = B + off["wb1"];
+  hw.Wa0p = head_packed ? B + off["Wa0p"] : nullptr;
+  hw.Wb0p = head_packed ? B + off["Wb0p"] : nullptr;
+  hw.W11p = head_packed ? B + off["W11p"] : nullptr;
+  hw.Wa1p = head_packed ? B + off["Wa1p"] : nullptr;
+  hw.Wa1Tp = head_packed ? B + off["Wa1Tp"] : nullptr;
+  hw.W11Tp = head_packed ? B + off["W11Tp"] : nullptr;
+  hw.Wb0Tp = head_packed ? B + off["Wb0Tp"] : nullptr;
+  hw.Wa0Tp = head_packed ? B + off["Wa0Tp"] : nullptr;
   hw.bb1 = (*bb1)[0];
   hw.mean = (*meanv)[0];
   hw.stdv = (*stdv)[0];
@@ -932,12 +962,16 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // products they feed (fused.hip) - g_t and the attention part of g_pe never reach HBM
     const bool panel = c->fuse_panel && !c->debug && !streamless && w.WsTp && bwd_batch_path(D) && panel_ok(D);
     if (panel) {
-      if (side_bw) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, st));
-        HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        if (!last) RC(launch_bwd_side(c->side, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo, c->g_vec, b.tpre, c->g_vh));
-        else RC(launch_bwd_vecmsg_S(c->side, D, c->g_vec, b.tpre, c->g_vh));
-        HIPCHK(c, hipEventRecord(c->ev_join, c->side));
+      // edge-update adjoints + source side of the vector messages: on the side stream, or (overlap off) in line
+      if (!l0) {
+        hipStream_t ss = side_bw ? c->side : st;
+        if (side_bw) {
+          HIPCHK(c, hipEventRecord(c->ev_fork, st));
+          HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        }
+        if (!last) RC(launch_bwd_side(ss, D, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_geo, c->g_vec, b.tpre, c->g_vh));
+        else RC(launch_bwd_vecmsg_S(ss, D, c->g_vec, b.tpre, c->g_vh));
+        if (side_bw) HIPCHK(c, hipEventRecord(c->ev_join, c->side));
       }
       RC(launch_bwd_gm_fused(st, D, c->g_vec, b.vh, b.tpre, w.WsTp, c->g_m, c->g_geo));
       RC(launch_gemm(st, c->g_o, 3 * H, w.WoT, 3 * H, c->g_A, H, nullptr, N, nullptr, H, 3 * H, 0));

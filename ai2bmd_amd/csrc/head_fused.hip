@@ -20,9 +20,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #endif
 #define HF_WAVES 16     // 1024 threads: 4 waves per SIMD of the one workgroup a CU holds (LDS-bound occupancy)
 
-// Out[r][n] = sum_k A[r][k] * W[n][k] (+ bias[n]) for r < M, n < Nc.  A, Out in LDS (row strides lda, ldo), W global
-// [Nc][ldw] (the nn.Linear layout, K contiguous).  Wave w owns the 16-column blocks w, w + 8, ...; for each it keeps
-// one accumulator per 16-row block (RB <= 4) so a weight fragment is fetched once and used for every row block.
+// Out[r][n] = sum_k A[r][k] * W[n][k] (+ bias[n]) for r < M, n < Nc.  A, Out in LDS (row strides lda, ldo), W global,
+// PACKED in fragment order at load time (engine.hip::pack_head): block (16 columns cb, 16 k kg) = 1 KiB = one coalesced
+// 16-byte load per lane (the nn.Linear layout cost a load instruction 16 half-used cache lines: the workgroup's
+// weight stream, not its MFMAs, is what a tile waits for).  Wave w owns the 16-column blocks w, w + 16, ...; for each
+// it keeps one accumulator per 16-row block (RB <= 4) so a weight fragment is fetched once and used for every row block.
 // MFMA 16x16x4: lane (i = lane & 15, q = lane >> 4) supplies A[i][k0 + 4 q + t] and W[n0 + i][k0 + 4 q + t] for
 // t = 0..3 (one 16-byte access each), i.e. 16 k-values per group of four MFMAs; result lane holds
 // C[4 q + r][n0 + i], r = 0..3.
@@ -46,17 +48,17 @@ __device__ __forceinline__ void lds_gemm(const float* __restrict__ As, int lda, 
     r = r < M ? r : M - 1;  // rows past the tile repeat its last row; their results are never stored
     ap[rb] = As + r * lda + q * 4;
   }
-  const float* wp = W + (size_t)(wave * 16 + i) * K + q * 4;
+  const float* wp = W + (size_t)wave * KG * 256 + lane * 4;  // block (cb = wave, kg = 0), this lane's 16 bytes
   f32x4v wq[PD];
 #pragma unroll
-  for (int p = 0; p < PD; ++p) wq[p] = *reinterpret_cast<const f32x4v*>(wp + p * 16);
+  for (int p = 0; p < PD; ++p) wq[p] = *reinterpret_cast<const f32x4v*>(wp + p * 256);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
   for (int j = 0; j < NCB; ++j) {
     const int cb = wave + j * HF_WAVES;
     if (cb >= CB) break;
     // the ring keeps running into the next column block of this wave (clamped to the current one at the end)
-    const float* wn = cb + HF_WAVES < CB ? wp + (size_t)HF_WAVES * 16 * K : wp;
+    const float* wn = cb + HF_WAVES < CB ? wp + (size_t)HF_WAVES * KG * 256 : wp;
     f32x4v acc[RB], an[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -66,8 +68,8 @@ __device__ __forceinline__ void lds_gemm(const float* __restrict__ As, int lda, 
 #pragma unroll
     for (int kg = 0; kg < KG; ++kg) {  // fully unrolled: every register index below is static
       const f32x4v w = wq[kg % PD];
-      wq[kg % PD] = kg + PD < KG ? *reinterpret_cast<const f32x4v*>(wp + (kg + PD) * 16)
-                                 : *reinterpret_cast<const f32x4v*>(wn + (kg + PD - KG) * 16);
+      wq[kg % PD] = kg + PD < KG ? *reinterpret_cast<const f32x4v*>(wp + (kg + PD) * 256)
+                                 : *reinterpret_cast<const f32x4v*>(wn + (kg + PD - KG) * 256);
       f32x4v ac[RB];
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {  // the A fragments one k-group ahead as well (LDS latency off the MFMA chain)
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S2: a0 = cat0 . Wa0^T + ba0 ; ta = act(a0)
-  lds_gemm<1, 2 * H, H>(cat0, l2H, M, a.W.Wa0, a.W.ba0, a0, lH, wave, lane);
+  lds_gemm<1, 2 * H, H>(cat0, l2H, M, a.W.Wa0p, a.W.ba0, a0, lH, wave, lane);
   __syncthreads();
   for (int idx = tid; idx < M * H; idx += nthr) {
     const int i = idx / H, c = idx - i * H;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S3: u0 = ta . Wb0^T + bb0 = [xs | gate]
-  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0, a.W.bb0, u0, lH, wave, lane);
+  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0p, a.W.bb0, u0, lH, wave, lane);
   __syncthreads();
   // S4: cat1[:, :h2] = act(xs) ; vec1o[s] = gate * pv0[s, H:]
   for (int idx = tid; idx < M * h2; idx += nthr) {
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S5: p1 = vec1o . W11^T
-  lds_gemm<RBV, h2, h2>(vec1o, lh, MR, a.W.W11, nullptr, p1, lh, wave, lane);
+  lds_gemm<RBV, h2, h2>(vec1o, lh, MR, a.W.W11p, nullptr, p1, lh, wave, lane);
   __syncthreads();
   // S6: cat1[:, h2:] = || p1 ||_s
   for (int idx = tid; idx < M * h2; idx += nthr) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S7: a1b = cat1 . Wa1^T + ba1
-  lds_gemm<1, H, h2>(cat1, lH, M, a.W.Wa1, a.W.ba1, a1b, lh, wave, lane);
+  lds_gemm<1, H, h2>(cat1, lH, M, a.W.Wa1p, a.W.ba1, a1b, lh, wave, lane);
   __syncthreads();
   // S8: y = std (wb1 . act(a1b) + bb1) + atomref[z] ; g_a1 = std wb1 act'(a1b)   (dE/dy = 1)
   if (wave < M) {
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S10: g_cat1 = g_a1 . Wa1
-  lds_gemm<1, h2, H>(a1b, lh, M, a.W.Wa1T, nullptr, gcat1, lH, wave, lane);
+  lds_gemm<1, h2, H>(a1b, lh, M, a.W.Wa1Tp, nullptr, gcat1, lH, wave, lane);
   __syncthreads();
   // S11: g_p1[s] = g_v1b / v1b * p1[s]   (0 where v1b == 0, like torch.norm)
   for (int idx = tid; idx < M * h2; idx += nthr) {
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S12: g_vec1o = g_p1 . W11
-  lds_gemm<RBV, h2, h2>(p1, lh, MR, a.W.W11T, nullptr, vec1o, lh, wave, lane);
+  lds_gemm<RBV, h2, h2>(p1, lh, MR, a.W.W11Tp, nullptr, vec1o, lh, wave, lane);
   __syncthreads();
   // S13: g_gate = sum_s g_vec1o[s] v2[s] ; g_v2[s] = g_vec1o[s] gate ; g_xs = g_x1 act'(xs)
   for (int idx = tid; idx < M * h2; idx += nthr) {
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S14: g_h0 = (g_u0 . Wb0) * act'(a0)
-  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0T, nullptr, cat1, lH, wave, lane);
+  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0Tp, nullptr, cat1, lH, wave, lane);
   __syncthreads();
   for (int idx = tid; idx < M * H; idx += nthr) {
     const int i = idx / H, c = idx - i * H;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   }
   __syncthreads();
   // S15: g_cat0 = g_h0 . Wa0
-  lds_gemm<1, H, 2 * H>(cat1, lH, M, a.W.Wa0T, nullptr, gcat0, l2H, wave, lane);
+  lds_gemm<1, H, 2 * H>(cat1, lH, M, a.W.Wa0Tp, nullptr, gcat0, l2H, wave, lane);
   __syncthreads();
   // S16: dE/d out_norm(x) -> global ; g_pv0[s, :H] = g_v1 / v1 * pv0[s, :H]
   for (int idx = tid; idx < M * H; idx += nthr) {
@@ -264,6 +266,7 @@ static size_t head_fused_lds(int H, int S) {
   return 4 * (2 * T * (2 * H + 4) + 5 * T * (H + 4) + 2 * R * (h2 + 4) + T * (h2 + 4));
 }
 
+// (the packed weight copies exist for H % 64 == 0, H <= 256: engine.hip)
 bool head_fused_supported(const Dims& D) {
   return (D.S == 3 || D.S == 8) && D.N < 4096 && (D.H == 64 || D.H == 128 || D.H == 192 || D.H == 256) &&
          head_fused_lds(D.H, D.S) <= 160 * 1024;

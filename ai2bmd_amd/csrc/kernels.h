@@ -208,6 +208,9 @@ struct HeadW {
   const float *Wb0, *bb0, *Wb0T;
   const float *W11, *W11T;
   const float *Wa1, *ba1, *Wa1T;
+  // the same matrices in the fused head's MFMA 16x16x4 fragment order (head_fused.hip::lds_gemm: 1-KiB blocks of 16
+  // columns x 16 k, one coalesced 16-byte load per lane); null when the fused head is not applicable
+  const float *Wa0p, *Wb0p, *W11p, *Wa1p, *Wa1Tp, *W11Tp, *Wb0Tp, *Wa0Tp;
   const float* wb1;  // [h2] row 0 of update_net.2 of block 1
   float bb1, mean, stdv;
   const float* atomref;  // [Z] or null

@@ -411,3 +411,34 @@ def test_visnet_model_positional_device_like_the_reference(lib_built, tmp_path):
     assert m.device == "cuda:0"
     e, f = m.dl_potential_loader(frag(g["z"], g["pos"], g["start"], g["end"]))
     check(e, f, g["E_ref64"], g["F_ref64"])
+
+
+def test_batch_path_option_matrix(lib_built):
+    """Fragment batch (N >= 4096, hidden 256: one wave per node, panel / fused products): the A/B switches of the
+    engine - side stream on / off, fused panel products on / off - change the schedule, never the result beyond fp32
+    round-off (an overlap=0 run once skipped the edge-update adjoints on the fused path)."""
+    hp = default_hparams(embedding_dimension=256, num_layers=3)
+    z1, p1, s1, e1 = random_fragments(6, [27, 12, 33])
+    reps = 80
+    n1 = len(z1)
+    z = np.tile(z1, reps)
+    pos = np.tile(p1, (reps, 1))
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    assert len(z) >= 4096
+    m = model_for(hp, 4)
+    ref = None
+    for overlap in (2, 0):
+        for fuse in (1, 0):
+            m.engine.set_option("overlap", overlap)
+            m.engine.set_option("fuse_panel", fuse)
+            e, f = m.dl_potential_loader(frag(z, pos, start, end))
+            if ref is None:
+                ref = (e, f)
+                E64, F64, _ = ViSNetOracle(hp, make_state_dict(hp, seed=4), torch.float64).energy_forces(z1, p1, s1, e1)
+                check(e.reshape(reps, -1)[0].reshape(-1, 1), f.reshape(reps, n1, 3)[0], E64, F64)
+            else:
+                np.testing.assert_allclose(e, ref[0], rtol=0, atol=2e-5)
+                np.testing.assert_allclose(f, ref[1], rtol=0, atol=2e-5)
+    m.engine.set_option("overlap", 2)
+    m.engine.set_option("fuse_panel", 1)
