@@ -92,8 +92,11 @@ struct vsn_ctx {
   std::vector<SRec> srecs;
   double prof_empty_ms = 0;   // profile mode: total time of EMPTY event brackets (the cost an event pair adds) ...
   double prof_empty_n = 0;    // ... and how many were measured
-  int64_t max_chunk_edges = 1572864;  // ~126 GB of workspace at H=256, L=9 (swept: 262144 -> 10.7k, 1048576 -> 11.7k frag/s; round 3:
-                                      // a 4096-fragment batch, 1.37 M edges, as ONE chunk instead of two: +0.9 %)
+  // edge SLOTS per chunk (host bound sum n*min(n, max_nb)); ~105 GB of workspace at H=256, L=9.  Swept on the
+  // 4096-fragment batch (1.9 M slots, 1.37 M edges), fragments/s: 262144 12.6k, 524288 13.0k, 786432 13.2k, 1048576 13.4k,
+  // 1310720 13.5k, 1572864 13.3k, 2097152 (ONE chunk, 170 GB) 12.0k - past ~1.3 M slots the per-layer arrays outgrow
+  // what the Infinity Cache / TLB reach keeps warm between producer and consumer kernels
+  int64_t max_chunk_edges = 1310720;
   // buffers
   int *fstart, *fend, *deg, *zi, *rowptr, *colptr, *src, *tgt, *perm, *ecount;
   float *geo, *d, *rbf, *drbf;

@@ -73,7 +73,7 @@ int vsn_load_weight(vsn_handle h, const char* name, const void* ptr, const int64
  * required tensor is missing. */
 int vsn_finalize(vsn_handle h);
 
-/* Options: "max_chunk_edges" (workspace bound, default 1572864 edge slots ~ 126 GB at H=256, L=9), "debug" (1 = keep per-layer
+/* Options: "max_chunk_edges" (workspace bound, default 1310720 edge slots ~ 105 GB at H=256, L=9), "debug" (1 = keep per-layer
  * snapshots for vsn_debug_read), "profile" (1 = time every GEMM launch, see vsn_profile_read), "overlap" (bit 0 / bit 1 =
  * run the forward / reverse side work on a second HIP stream, default 2), "fuse_fwd", "fuse_bwd" (vertical fusions,
  * default 1), "fuse_head" (one-launch node-local read-out on single-protein sizes, default 1), "split_rev" (K-slices
