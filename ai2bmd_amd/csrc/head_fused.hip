@@ -18,6 +18,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef HF_T
 #define HF_T 8          // nodes per workgroup (A/B builds: -DHF_T=4)
 #endif
+#ifndef HF_PD
+#define HF_PD 8         // weight fragments (1 KiB each) in flight per wave (A/B builds: -DHF_PD=16)
+#endif
 #define HF_WAVES 16     // 1024 threads: 4 waves per SIMD of the one workgroup a CU holds (LDS-bound occupancy)
 
 // Out[r][n] = sum_k A[r][k] * W[n][k] (+ bias[n]) for r < M, n < Nc.  A, Out in LDS (row strides lda, ldo), W global,
@@ -35,8 +38,8 @@ __device__ __forceinline__ void lds_gemm(const float* __restrict__ As, int lda, 
   constexpr int KG = K / 16, CB = NC / 16;
   // weight fragments in flight per wave (an L2 round trip spans ~8 k-groups): the largest divisor of KG up to 8, so
   // that the ring slot of fragment kg is kg % PD in EVERY column block (the ring runs on across block boundaries)
-  constexpr int PD = KG % 8 == 0 ? 8 : KG % 7 == 0 ? 7 : KG % 6 == 0 ? 6 : KG % 5 == 0 ? 5 : KG % 4 == 0 ? 4
-                   : KG % 3 == 0 ? 3 : KG % 2 == 0 ? 2 : 1;
+  constexpr int PD = KG % HF_PD == 0 ? HF_PD : KG % 8 == 0 ? 8 : KG % 7 == 0 ? 7 : KG % 6 == 0 ? 6 : KG % 5 == 0 ? 5
+                   : KG % 4 == 0 ? 4 : KG % 3 == 0 ? 3 : KG % 2 == 0 ? 2 : 1;
   static_assert(KG % PD == 0, "ring depth must divide the k-groups of a column block");
   constexpr int NCB = (CB + HF_WAVES - 1) / HF_WAVES;
   const int i = lane & 15, q = lane >> 4;
