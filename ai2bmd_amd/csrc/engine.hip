@@ -847,7 +847,18 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   RC(launch_gemm(st, c->rbf, Rp, c->Wrbf, Rp, c->pp, 2 * H, c->brbf, Emax, EP, 2 * H, Rp, 0));
   RC(launch_embed_node(st, D, c->emb1, c->emb2, c->pp, c->cat));
   RC(launch_gemm(st, c->cat, 2 * H, c->Wc, 2 * H, c->x_emb, H, c->bc, N, nullptr, H, 2 * H, 0));
-  RC(launch_embed_edge(st, D, c->x_emb, c->pp, c->f, c->vec, c->x));
+  // layer 0's LayerNorm (and vh = 0 under VecLayerNorm "none") rides in the edge-embedding launch
+  const bool fuse_norm0 = c->fuse_fwd && c->hp.vecnorm_type == 0 && !c->debug;
+  {
+    NextNorm n0;
+    memset(&n0, 0, sizeof(n0));
+    if (fuse_norm0) {
+      const LayerW& w0 = c->lw[0];
+      LayerBuf& b0 = c->lb[0];
+      n0 = NextNorm{w0.ln_g, w0.ln_b, w0.vln_w, b0.xn, b0.rstd, c->xh, b0.vh, H};
+    }
+    RC(launch_embed_edge(st, D, c->x_emb, c->pp, c->f, c->vec, c->x, n0));
+  }
   // ---- ViS-MP layers ----
   for (int l = 0; l < L; ++l) {
     const bool last = (l == L - 1);
@@ -859,7 +870,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // the norms of layer l > 0 (and of the read-out) were already produced by the node update of layer l-1
     // when the fusion is active (vecnorm "none", not in debug mode)
     const bool fuse_norm = c->fuse_fwd && c->hp.vecnorm_type == 0 && !c->debug;
-    if (!fuse_norm || l == 0) {
+    if (!fuse_norm) {
       RC(launch_node_norm(st, D, c->x, c->vec, w.ln_g, w.ln_b, w.vln_w, c->hp.vecnorm_type, b.xn, b.rstd, c->xh, H,
                           b.vh));
       if (c->hp.vecnorm_type) RC(launch_vecnorm_fwd(st, N, H, S, c->hp.vecnorm_type, c->vec, w.vln_w, b.vin, b.vh));
@@ -1056,7 +1067,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (fuse_bwd && l > 0)  // norm adjoint of this layer + node-update adjoint of the layer below, one pass
       RC(launch_bwd_norm_update(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, 1, c->g_x, c->g_vec,
                                 c->lb[l - 1].vp, c->lb[l - 1].o, c->g_o, c->g_vp));
-    else
+    else if (!(fuse_bwd && l0))  // (fused reverse pass: layer 0's LayerNorm adjoint rides in the edge-embedding adjoint)
       RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
                               l0 ? 3 /* skip the vec part */ : c->hp.vecnorm_type, 1, c->g_x, c->g_vec));
     // layer 0 normalises vec == 0, which does not depend on the positions: nothing to propagate
@@ -1067,7 +1078,11 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     snapshot(c, st, "g_f_in", l, c->g_f, (size_t)Emax * H);
   }
   // ---- embeddings, reverse ----
-  RC(launch_bwd_embed_edge(st, D, c->x_emb, c->pp, c->g_f, c->g_pp, c->g_x));
+  if (fuse_bwd)
+    RC(launch_bwd_embed_edge(st, D, c->x_emb, c->pp, c->g_f, c->g_pp, c->g_x, c->g_xh, c->lb[0].xn, c->lb[0].rstd,
+                             c->lw[0].ln_g));
+  else
+    RC(launch_bwd_embed_edge(st, D, c->x_emb, c->pp, c->g_f, c->g_pp, c->g_x, nullptr, nullptr, nullptr, nullptr));
   RC(launch_gemm(st, c->g_x, H, c->WcnT, H, c->g_n, H, nullptr, N, nullptr, H, H, 0));
   RC(launch_bwd_embed_node(st, D, c->emb2, c->pp, c->g_n, c->g_pp, c->g_geo));
   RC(launch_gemm(st, c->g_pp, 2 * H, c->WrbfT, 2 * H, c->g_rbf, Rp, nullptr, Emax, EP, Rp, 2 * H, 0));

@@ -306,27 +306,4 @@ int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const f
   return 0;
 }
 
-// plain panel products (fragment batches, hidden 256): fwd K == 256, bwd Nc == 256
-int launch_pgemm_fwd(hipStream_t st, const float* A, int lda, const float* Bp, float* C, int ldc, const float* bias,
-                     int M, const int* Mptr, int Nc, int accumulate) {
-  if (M <= 0) return 0;
-  if ((Nc & 127) || (lda & 3) || (ldc & 3)) return -22;
-  const int grid = (M + 63) / 64;
-#define VSN_PF(E_)                                                                                          \
-  do {                                                                                                      \
-    panel_lds(k_pgemm_fwd<2, 4, 8, E_>);                                                                    \
-    k_pgemm_fwd<2, 4, 8, E_><<<grid, 256, 65536, st>>>(A, lda, Bp, C, ldc, bias, M, Mptr, Nc, 1);           \
-  } while (0)
-  if (accumulate) {
-    if (bias) return -22;
-    VSN_PF(2);
-  } else if (bias) {
-    VSN_PF(1);
-  } else {
-    VSN_PF(0);
-  }
-#undef VSN_PF
-  return 0;
-}
-
 }  // namespace vsn

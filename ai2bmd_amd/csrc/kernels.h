@@ -125,12 +125,6 @@ int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, cons
 // ---- forward ----
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
                       float* cat);
-int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec,
-                      float* xcopy);
-int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
-                     const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
-                     int ldxh, float* vh);
-int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A);
 // LayerNorm + VecLayerNorm("none") of the NEXT layer (or the read-out) fused into the node update that
 // produces their input; xn == nullptr disables the fusion
 struct NextNorm {
@@ -138,6 +132,13 @@ struct NextNorm {
   float *xn, *rstd, *xh, *vh;
   int ldxh;
 };
+// nn.xn != nullptr: layer 0's norms (LayerNorm of x; vh = 0) ride in the same launch
+int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec,
+                      float* xcopy, const NextNorm& nn);
+int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
+                     const float* beta, const float* wvec, int norm_type, float* xn, float* rstd, float* xh,
+                     int ldxh, float* vh);
+int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A);
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
                        const float* o, float* x, float* vec, const NextNorm& nn);
 // adjoint of LayerNorm (+ VecLayerNorm "none") of layer l fused with the adjoint of the node update of
@@ -191,13 +192,13 @@ int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const
 int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A,
                         float* g_m, const float* g_pe, float* sat_tmp, float* g_geo, const float* We3Tp, float* g_f,
                         int K, int accumulate);
-int launch_pgemm_fwd(hipStream_t st, const float* A, int lda, const float* Bp, float* C, int ldc, const float* bias,
-                     int M, const int* Mptr, int Nc, int accumulate);
 int launch_bwd_node_norm(hipStream_t st, const Dims& D, const float* g_xh, int ldg, const float* g_vh, const float* xn,
                          const float* rstd, const float* gamma, const float* wvec, int norm_type, int accumulate,
                          float* g_x, float* g_vec);
+// g_xh != nullptr: layer 0's LayerNorm adjoint (g_x += ...) rides in the same launch
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
-                          float* g_pp, float* g_x);
+                          float* g_pp, float* g_x, const float* g_xh, const float* xn, const float* rstd,
+                          const float* gamma);
 int launch_bwd_embed_node(hipStream_t st, const Dims& D, const float* emb2, const float* pp, const float* g_n,
                           float* g_pp, float* g_geo);
 

@@ -949,10 +949,12 @@ __global__ __launch_bounds__(WPN == 1 ? 256 : 64 * WPN) void k_bwd_norm_update(D
 
 // ---- adjoint of EdgeEmbedding (utils.py:331-337) -----------------------------------
 // g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
+// g_xh != nullptr: the LayerNorm adjoint of layer 0 (what k_bwd_node_norm adds to g_x) rides in the node epilogue
 template <int V, int S, int WPN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
     Dims D, const float* __restrict__ x, const float* __restrict__ pp, const float* __restrict__ g_f,
-    float* __restrict__ g_pp, float* __restrict__ g_x) {
+    float* __restrict__ g_pp, float* __restrict__ g_x, const float* __restrict__ g_xh,
+    const float* __restrict__ xn, const float* __restrict__ rstd, const float* __restrict__ gamma) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
@@ -988,6 +990,24 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
     if (sub == 0) {
       float gx[V];
       ldrow<V>(g_x + (size_t)i * H, lane, gx);
+      if (g_xh) {  // same arithmetic and order as k_bwd_node_norm (accumulate): g_x += rstd (g - mean(g) - n mean(g n))
+        float g[V], n[V], ga[V];
+        ldrow<V>(g_xh + (size_t)i * H, lane, g);
+        ldrow<V>(xn + (size_t)i * H, lane, n);
+        ldrow<V>(gamma, lane, ga);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          g[c] *= ga[c];
+          s1 += g[c];
+          s2 += g[c] * n[c];
+        }
+        const float invH = 1.0f / (float)H;
+        const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+        const float rs = rstd[i];
+#pragma unroll
+        for (int c = 0; c < V; ++c) gx[c] += rs * (g[c] - m1 - n[c] * m2);
+      }
 #pragma unroll
       for (int c = 0; c < V; ++c) gx[c] += acc[0][c];
       strow<V>(g_x + (size_t)i * H, lane, gx);
@@ -1183,9 +1203,10 @@ int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,
-                          float* g_pp, float* g_x) {
+                          float* g_pp, float* g_x, const float* g_xh, const float* xn, const float* rstd,
+                          const float* gamma) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_bwd_embed_edge, 1, D, x, pp, g_f, g_pp, g_x);
+  VSN_LAUNCH(k_bwd_embed_edge, 1, D, x, pp, g_f, g_pp, g_x, g_xh, xn, rstd, gamma);
   return 0;
 }
 int launch_bwd_embed_node(hipStream_t st, const Dims& D, const float* emb2, const float* pp, const float* g_n,

@@ -113,6 +113,34 @@ static inline size_t node_lds(int wpn, int K, int V) {
   return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
 }
 
+// fused LayerNorm of the NEXT layer / read-out on one node row held by a wave (same arithmetic as k_node_norm)
+template <int V>
+__device__ __forceinline__ void node_layernorm_store(const NextNorm& nn, int i, int H, int lane, float (&xv)[V]) {
+  const float invH = 1.0f / (float)H;
+  float g[V], bta[V], sm_ = 0.f;
+  ldrow<V>(nn.gamma, lane, g);
+  ldrow<V>(nn.beta, lane, bta);
+#pragma unroll
+  for (int c = 0; c < V; ++c) sm_ += xv[c];
+  const float mean = wave_sum(sm_) * invH;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    xv[c] -= mean;
+    q += xv[c] * xv[c];
+  }
+  const float rs = 1.0f / sqrtf(wave_sum(q) * invH + 1e-5f);
+  float n[V], hh[V];
+#pragma unroll
+  for (int c = 0; c < V; ++c) {
+    n[c] = xv[c] * rs;
+    hh[c] = n[c] * g[c] + bta[c];
+  }
+  strow<V>(nn.xn + (size_t)i * H, lane, n);
+  strow<V>(nn.xh + (size_t)i * nn.ldxh, lane, hh);
+  if (lane == 0) nn.rstd[i] = rs;
+}
+
 // ---- embeddings -------------------------------------------------------------
 // cat[i] = [ emb1[z_i] | sum_{j->i, j!=i} emb2[z_j] * phi_e * C_e ]   (utils.py:296-317)
 template <int V, int S, int WPN>
@@ -149,12 +177,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_node(Dims D
 }
 
 // f_e = (x_i + x_j) * psi_e for all edges incl. loops (utils.py:331-337); vec = 0
+// nn.xn != nullptr: also layer 0's LayerNorm of x and its VecLayerNorm("none") of vec == 0 (vh = 0), i.e. what
+// k_node_norm would do in a launch of its own
 template <int V, int S, int WPN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D, const float* __restrict__ x,
                                                                           const float* __restrict__ pp,
                                                                           float* __restrict__ f,
                                                                           float* __restrict__ vec,
-                                                                          float* __restrict__ xcopy) {
+                                                                          float* __restrict__ xcopy, NextNorm nn) {
   const int H = D.H;
   VSN_NODE_LOOP(i, D.N, WPN) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
@@ -162,6 +192,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D
     float xi[V];
     ldrow<V>(x + (size_t)i * H, lane, xi);
     if (sub == 0) strow<V>(xcopy + (size_t)i * H, lane, xi);  // running x of the layers starts as a copy
+    if (nn.xn && sub == (WPN == 1 ? 0 : WPN - 1)) {  // (the last wave: it has the fewest edges of the node)
+      float xv[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) xv[c] = xi[c];
+      node_layernorm_store<V>(nn, i, H, lane, xv);
+    }
     for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
       float xj[V], ps[V], o[V];
@@ -174,7 +210,10 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D
     float zr[V];
 #pragma unroll
     for (int c = 0; c < V; ++c) zr[c] = 0.f;
-    for (int s = sub; s < S; s += WPN) strow<V>(vec + ((size_t)i * S + s) * H, lane, zr);
+    for (int s = sub; s < S; s += WPN) {
+      strow<V>(vec + ((size_t)i * S + s) * H, lane, zr);
+      if (nn.xn) strow<V>(nn.vh + ((size_t)i * S + s) * H, lane, zr);
+    }
   }
 }
 
@@ -274,34 +313,6 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D,
                                                                          float* __restrict__ A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   edge_attn_body<V, S, WPN, GEN>(D, qkv, pe, m, A, smem, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// fused LayerNorm of the NEXT layer / read-out on one node row held by a wave (same arithmetic as k_node_norm)
-template <int V>
-__device__ __forceinline__ void node_layernorm_store(const NextNorm& nn, int i, int H, int lane, float (&xv)[V]) {
-  const float invH = 1.0f / (float)H;
-  float g[V], bta[V], sm_ = 0.f;
-  ldrow<V>(nn.gamma, lane, g);
-  ldrow<V>(nn.beta, lane, bta);
-#pragma unroll
-  for (int c = 0; c < V; ++c) sm_ += xv[c];
-  const float mean = wave_sum(sm_) * invH;
-  float q = 0.f;
-#pragma unroll
-  for (int c = 0; c < V; ++c) {
-    xv[c] -= mean;
-    q += xv[c] * xv[c];
-  }
-  const float rs = 1.0f / sqrtf(wave_sum(q) * invH + 1e-5f);
-  float n[V], hh[V];
-#pragma unroll
-  for (int c = 0; c < V; ++c) {
-    n[c] = xv[c] * rs;
-    hh[c] = n[c] * g[c] + bta[c];
-  }
-  strow<V>(nn.xn + (size_t)i * H, lane, n);
-  strow<V>(nn.xh + (size_t)i * nn.ldxh, lane, hh);
-  if (lane == 0) nn.rstd[i] = rs;
 }
 
 // ---- vector messages, their aggregation and the node update ---------------------
@@ -534,9 +545,9 @@ int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const fl
   return 0;
 }
 int launch_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, float* f, float* vec,
-                      float* xcopy) {
+                      float* xcopy, const NextNorm& nn) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH(k_embed_edge, 0, D, x, pp, f, vec, xcopy);
+  VSN_LAUNCH(k_embed_edge, 0, D, x, pp, f, vec, xcopy, nn);
   return 0;
 }
 int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float* vec, const float* gamma,
