@@ -122,6 +122,7 @@ struct vsn_ctx {
   bool fuse_head = true;  // fused node-local head kernel (head_fused.hip) on single-protein sizes
   bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
   bool fuse_panel = true;  // fragment batches, hidden 256: gather kernels as prologues of panel GEMMs (fused.hip)
+  int64_t panel_min_edges = (int64_t)1 << 40;  // ... and below the batch regime from this many edge slots on (A/B aid: off)
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -236,6 +237,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->split_rev = value != 0;
   } else if (k == "fuse_panel") {
     c->fuse_panel = value != 0;
+  } else if (k == "panel_min_edges") {
+    c->panel_min_edges = value;
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -970,11 +973,14 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // single-protein sizes: no second stream at all - the same kernels ride in two launches of the main chain
     // (k_bwd_hf1 before the g_m / g_A products, k_bwd_hf2 after them); a fork/join costs ~7 us on the main stream at
     // each end, every layer
-    const bool streamless = (c->overlap & 2) && !c->debug && !l0 && bwd_streamless_ok(D);
-    const bool side_bw = (c->overlap & 2) && !c->debug && !l0 && !streamless;
     // fragment batches at hidden 256: the target-side vector-message and attention adjoints are prologues of the
-    // products they feed (fused.hip) - g_t and the attention part of g_pe never reach HBM
-    const bool panel = c->fuse_panel && !c->debug && !streamless && w.WsTp && bwd_batch_path(D) && panel_ok(D);
+    // products they feed (fused.hip) - g_t and the attention part of g_pe never reach HBM.  Below `panel_min_edges`
+    // (single-protein sizes) the 64-edge panels cannot fill the chip and the several-waves-per-node kernels stay.
+    const bool panel = c->fuse_panel && !c->debug && w.WsTp && panel_ok(D) &&
+                       (bwd_batch_path(D) || (int64_t)Emax >= c->panel_min_edges);
+    const bool streamless = (c->overlap & 2) && !c->debug && !l0 && bwd_streamless_ok(D) && !panel;
+    // (a second stream only pays on batches: its fork / join costs ~7 us at each end, every layer)
+    const bool side_bw = (c->overlap & 2) && !c->debug && !l0 && !streamless && bwd_batch_path(D);
     if (panel) {
       // edge-update adjoints + source side of the vector messages: on the side stream, or (overlap off) in line
       if (!l0) {

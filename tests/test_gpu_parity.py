@@ -413,11 +413,14 @@ def test_visnet_model_positional_device_like_the_reference(lib_built, tmp_path):
     check(e, f, g["E_ref64"], g["F_ref64"])
 
 
-def test_batch_path_option_matrix(lib_built):
+@pytest.mark.parametrize("acts", [None, ("ssp", "tanh")])
+def test_batch_path_option_matrix(lib_built, acts):
     """Fragment batch (N >= 4096, hidden 256: one wave per node, panel / fused products): the A/B switches of the
     engine - side stream on / off, fused panel products on / off - change the schedule, never the result beyond fp32
-    round-off (an overlap=0 run once skipped the edge-update adjoints on the fused path)."""
-    hp = default_hparams(embedding_dimension=256, num_layers=3)
+    round-off (an overlap=0 run once skipped the edge-update adjoints on the fused path).  Second case: the generic
+    activation table inside the fused prologues."""
+    over = dict(activation=acts[0], attn_activation=acts[1]) if acts else {}
+    hp = default_hparams(embedding_dimension=256, num_layers=3, **over)
     z1, p1, s1, e1 = random_fragments(6, [27, 12, 33])
     reps = 80
     n1 = len(z1)
