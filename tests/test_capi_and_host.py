@@ -179,3 +179,18 @@ def test_bench_self_launches_its_ranks_and_reports_one_line():
     assert out["steps_requested"] == 5 and out["steps"] >= 5 and out["data"] == "STUB"
     # rank 1 sleeps 4 ms per step, rank 0 only 2 ms: the reported time is the MAX over the ranks
     assert out["ms_per_step"] >= 3.9
+
+
+def test_hparams_of_module_reads_scripted_activation_names():
+    """load_model returns torch.jit.script(model) in the reference (visnet.py:92): a scripted sub-module reports its
+    class through `original_name`, not through type(...).__name__"""
+    from ai2bmd_amd.visnet_calculator import _act_name
+
+    class Scripted:  # what a RecursiveScriptModule exposes
+        original_name = "ShiftedSoftplus"
+
+    import torch
+
+    assert _act_name(Scripted()) == "ssp" and _act_name(torch.nn.SiLU()) == "silu" and _act_name(torch.nn.Tanh()) == "tanh"
+    with pytest.raises(TypeError):
+        _act_name(torch.nn.ReLU())
