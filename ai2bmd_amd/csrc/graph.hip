@@ -80,24 +80,50 @@ __global__ __launch_bounds__(1024) void k_scan(const int* __restrict__ deg, int*
 // Small-fragment variant of pass 2 (n <= 64, every AI2BMD fragment): one wave per fragment,
 // positions and the dense n x n edge-id matrix live in LDS, so the by-source view needs no
 // searches: thread j just walks column j in ascending target order.
+// SCAN (single-protein sizes, N < 4096): the wave also derives its rows of rowptr itself - base = sum of deg over all
+// earlier atoms (a few hundred to a few thousand ints), then the prefix inside the fragment - so the one-block k_scan
+// launch between the degree count and this kernel disappears (every launch of the MD step sits at a ~5 us floor).
+template <bool SCAN>
 __global__ __launch_bounds__(64) void k_graph_fill_small(const float* __restrict__ pos,
                                                          const int* __restrict__ fstart,
-                                                         const int* __restrict__ fend,
-                                                         const int* __restrict__ rowptr, int* __restrict__ src,
-                                                         int* __restrict__ tgt, int* __restrict__ colptr,
-                                                         int* __restrict__ perm, float rc2, int max_nb) {
+                                                         const int* __restrict__ fend, int* __restrict__ rowptr,
+                                                         int* __restrict__ src, int* __restrict__ tgt,
+                                                         int* __restrict__ colptr, int* __restrict__ perm, float rc2,
+                                                         int max_nb, const int* __restrict__ deg, int B, int N,
+                                                         int* __restrict__ ecount) {
   __shared__ float ps[64 * 3];
   __shared__ int eid[64 * 65];  // eid[i*65 + j] = edge (j -> i) or -1 ; padded against bank conflicts
   __shared__ int outdeg[64];
   const int b = blockIdx.x;
   const int s = fstart[b], n = fend[b] - s;
-  if (n <= 0) return;
   const int t = threadIdx.x;
+  int my_row = 0, base = 0;
+  if (SCAN) {
+    int part = 0;
+    for (int a = t; a < s; a += 64) part += deg[a];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    base = part;
+    const int dv = t < n ? deg[s + t] : 0;
+    int incl = dv;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (t >= o) incl += v;
+    }
+    my_row = base + incl - dv;
+    if (t < n) rowptr[s + t] = my_row;
+    if (b == B - 1 && t == 63) {  // the last fragment (possibly empty) closes the arrays: incl of lane 63 = its edge total
+      rowptr[N] = base + incl;
+      colptr[N] = base + incl;
+      *ecount = base + incl;
+    }
+  }
+  if (n <= 0) return;
   for (int k = t; k < 3 * n; k += 64) ps[k] = pos[3 * (size_t)s + k];
   __syncthreads();
   if (t < n) {
     const int i = t;
-    int e = rowptr[s + i];
+    int e = SCAN ? my_row : rowptr[s + i];
     int cnt = 0;
     const float xi = ps[3 * i], yi = ps[3 * i + 1], zi_ = ps[3 * i + 2];
     for (int j = 0; j < n; ++j) {
@@ -127,7 +153,7 @@ __global__ __launch_bounds__(64) void k_graph_fill_small(const float* __restrict
     if (t >= o) incl += v;
   }
   if (t < n) {
-    int out = rowptr[s] + incl - cnt;
+    int out = (SCAN ? base : rowptr[s]) + incl - cnt;
     colptr[s + t] = out;
     for (int i = 0; i < n; ++i) {
       const int e = eid[i * 65 + t];
@@ -372,9 +398,14 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.max_frag <= 64) {
     hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
                        a.max_nb, a.z_limit, a.status, a.epoch);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
-    hipLaunchKernelGGL(k_graph_fill_small, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr, a.src,
-                       a.tgt, a.colptr, a.perm, a.rc2, a.max_nb);
+    if (a.N < 4096) {  // single-protein sizes: the fill kernel scans the degrees itself (one launch less)
+      hipLaunchKernelGGL(k_graph_fill_small<true>, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr,
+                         a.src, a.tgt, a.colptr, a.perm, a.rc2, a.max_nb, a.deg, a.B, a.N, a.ecount);
+    } else {
+      hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, a.deg, a.rowptr, a.colptr, a.N, a.ecount);
+      hipLaunchKernelGGL(k_graph_fill_small<false>, dim3(a.B), dim3(64), 0, st, a.pos, a.fstart, a.fend, a.rowptr,
+                         a.src, a.tgt, a.colptr, a.perm, a.rc2, a.max_nb, a.deg, a.B, a.N, a.ecount);
+    }
   } else {
     // a fragment larger than a wavefront somewhere in the batch: node-parallel passes (any mix of sizes)
     const dim3 grid((a.N + 255) / 256), blk(256);
