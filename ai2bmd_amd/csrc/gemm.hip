@@ -344,16 +344,15 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
 }
 
 // split-K epilogue: C (+)= sum_s part[s] (+ bias), fixed summation order
-__global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float* __restrict__ C, int ldc,
-                              const float* __restrict__ bias, int M, const int* __restrict__ Mptr, int Nc,
-                              int flags) {
+__device__ __forceinline__ void gemm_reduce_body(const float* __restrict__ part, int ksplit, float* __restrict__ C,
+                                                 int ldc, const float* __restrict__ bias, int M,
+                                                 const int* __restrict__ Mptr, int Nc, int flags, long long gid) {
   int Meff = M;
   if (Mptr) {
     int md = *Mptr;
     Meff = md < M ? md : M;
   }
   const int nc4 = Nc >> 2;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long row = gid / nc4;
   const int c4 = (int)(gid % nc4);
   if (row >= Meff) return;
@@ -364,6 +363,24 @@ __global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float*
   float* cp = C + (size_t)row * ldc + c4 * 4;
   if (flags & 1) s += *reinterpret_cast<const f32x4*>(cp);
   *reinterpret_cast<f32x4*>(cp) = s;
+}
+__global__ void k_gemm_reduce(const float* __restrict__ part, int ksplit, float* __restrict__ C, int ldc,
+                              const float* __restrict__ bias, int M, const int* __restrict__ Mptr, int Nc,
+                              int flags) {
+  gemm_reduce_body(part, ksplit, C, ldc, bias, M, Mptr, Nc, flags, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// the split members of one grouped launch, summed in ONE launch (`blocks` = reduction workgroups of the member)
+__global__ void k_gemm_reduce_group(GemmGroup g) {
+  int b = (int)blockIdx.x, p = 0;
+#pragma unroll
+  for (int q = 0; q < GemmGroup::MAXP - 1; ++q)
+    if (p == q && q + 1 < g.n && b >= g.p[q].blocks) {
+      b -= g.p[q].blocks;
+      p = q + 1;
+    }
+  const GemmDesc& d = g.p[p];
+  gemm_reduce_body(d.part, d.ksplit, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.flags,
+                   (long long)b * blockDim.x + threadIdx.x);
 }
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
@@ -592,11 +609,21 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
   if (g.n > 0) {
     hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
   }
-  for (int i = 0; i < nred; ++i) {
-    const GemmDesc& d = red[i];
+  if (nred == 1) {
+    const GemmDesc& d = red[0];
     long long n4 = (long long)d.M * (d.Nc / 4);
     hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, d.part, d.ksplit, d.C,
                        d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.flags);
+  } else if (nred > 1) {
+    GemmGroup r;
+    r.n = nred;
+    unsigned rgrid = 0;
+    for (int i = 0; i < nred; ++i) {
+      r.p[i] = red[i];
+      r.p[i].blocks = (int)(((long long)red[i].M * (red[i].Nc / 4) + 255) / 256);
+      rgrid += (unsigned)r.p[i].blocks;
+    }
+    hipLaunchKernelGGL(k_gemm_reduce_group, dim3(rgrid), dim3(256), 0, st, r);
   }
   if (rec) hipEventRecord(rec->b, st);
   return 0;
