@@ -21,6 +21,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #ifndef HF_PD
 #define HF_PD 8         // weight fragments (1 KiB each) in flight per wave (A/B builds: -DHF_PD=16)
 #endif
+static_assert(HF_T <= 8, "lds_gemm8 carries two 4-row groups");
 #define HF_WAVES 16     // 1024 threads: 4 waves per SIMD of the one workgroup a CU holds (LDS-bound occupancy)
 
 // Out[r][n] = sum_k A[r][k] * W[n][k] (+ bias[n]) for r < M, n < Nc.  A, Out in LDS (row strides lda, ldo), W global,
@@ -104,6 +105,86 @@ __device__ __forceinline__ void lds_gemm(const float* __restrict__ As, int lda, 
   }
 }
 
+// The same product for the SCALAR stages (M <= 8 rows: one row per node of the tile).  A 16-row MFMA would spend half
+// of its passes on padding rows, and the matrix pipe of the ONE CU a tile lives on is what these stages wait for
+// (15 stages = 18.9 MFLOP padded, 30 us of a CU's fp32 pipe); v_mfma_f32_4x4x1_16B_f32 has sixteen independent 4 x 4
+// blocks instead: block b = 4 kk + cg takes rows (4 g .. 4 g + 3) x columns (4 cg .. 4 cg + 3) of the wave's 16-column
+// block and the k-subset (4 kk .. 4 kk + 3) of every 16-k group, two row groups g = all 8 rows, nothing padded; the
+// four k-subsets are summed across lanes l, l + 16, l + 32, l + 48 at the end of a column block.  The lane's weight
+// operand is W[n0 + (lane & 15)][k0 + 4 (lane >> 4) + t] - exactly the packed fragment the 16x16x4 form reads.
+template <int K, int NC>
+__device__ __forceinline__ void lds_gemm8(const float* __restrict__ As, int lda, int M, const float* __restrict__ W,
+                                          const float* __restrict__ bias, float* __restrict__ Out, int ldo, int wave,
+                                          int lane) {
+  constexpr int KG = K / 16, CB = NC / 16;
+  constexpr int PD = KG % HF_PD == 0 ? HF_PD : KG % 8 == 0 ? 8 : KG % 7 == 0 ? 7 : KG % 6 == 0 ? 6 : KG % 5 == 0 ? 5
+                   : KG % 4 == 0 ? 4 : KG % 3 == 0 ? 3 : KG % 2 == 0 ? 2 : 1;
+  static_assert(KG % PD == 0, "ring depth must divide the k-groups of a column block");
+  constexpr int NCB = (CB + HF_WAVES - 1) / HF_WAVES;
+  const int c = lane & 15, kk = lane >> 4, i = lane & 3;
+  if (wave >= CB) return;
+  const float* ap0 = As + (i < M ? i : M - 1) * lda + kk * 4;          // rows past the tile repeat its last row
+  const float* ap1 = As + (4 + i < M ? 4 + i : M - 1) * lda + kk * 4;  // (never stored)
+  const float* wp = W + (size_t)wave * KG * 256 + lane * 4;
+  f32x4v wq[PD];
+#pragma unroll
+  for (int p = 0; p < PD; ++p) wq[p] = *reinterpret_cast<const f32x4v*>(wp + p * 256);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+  for (int j = 0; j < NCB; ++j) {
+    const int cb = wave + j * HF_WAVES;
+    if (cb >= CB) break;
+    const float* wn = cb + HF_WAVES < CB ? wp + (size_t)HF_WAVES * KG * 256 : wp;
+    f32x4v acc0 = f32x4v{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    f32x4v an0 = *reinterpret_cast<const f32x4v*>(ap0), an1 = *reinterpret_cast<const f32x4v*>(ap1);
+#pragma unroll
+    for (int kg = 0; kg < KG; ++kg) {
+      const f32x4v w = wq[kg % PD];
+      wq[kg % PD] = kg + PD < KG ? *reinterpret_cast<const f32x4v*>(wp + (kg + PD) * 256)
+                                 : *reinterpret_cast<const f32x4v*>(wn + (kg + PD - KG) * 256);
+      const f32x4v a0 = an0, a1 = an1;
+      an0 = *reinterpret_cast<const f32x4v*>(ap0 + (kg + 1 < KG ? kg + 1 : 0) * 16);
+      an1 = *reinterpret_cast<const f32x4v*>(ap1 + (kg + 1 < KG ? kg + 1 : 0) * 16);
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, w.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, w.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, w.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, w.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, w.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, w.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, w.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, w.w, acc1, 0, 0, 0);
+    }
+    const int col = cb * 16 + c;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v0 = acc0[r], v1 = acc1[r];
+      v0 += __shfl_xor(v0, 16);
+      v1 += __shfl_xor(v1, 16);
+      v0 += __shfl_xor(v0, 32);
+      v1 += __shfl_xor(v1, 32);
+      if (kk == 0) {
+        if (r < M) Out[r * ldo + col] = v0 + bv;
+        if (4 + r < M) Out[(4 + r) * ldo + col] = v1 + bv;
+      }
+    }
+    wp = wn;
+  }
+}
+
+// Lab builds (-DHF_LAB_STAMPS): thread 0 of every workgroup stamps the 100 MHz real-time counter after each stage into a
+// buffer set with vsn_lab_set_hf_stamps() (tools/lab/stamps_head.py prints the stage times).
+#ifdef HF_LAB_STAMPS
+__device__ unsigned long long* g_hf_stamps = nullptr;
+#define HF_STAMP(k)                                                                                 \
+  do {                                                                                              \
+    if (g_hf_stamps && threadIdx.x == 0) g_hf_stamps[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define HF_STAMP(k) do {} while (0)
+#endif
+
 struct HeadFusedArgs {
   int N, S, H, act;
   const float* cat0g;   // [N][2H], first H columns = out_norm(x)
@@ -137,6 +218,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
   const int n0 = blockIdx.x * T;
   const int M = a.N - n0 < T ? a.N - n0 : T;  // live nodes of this tile
   const int MR = M * S;
+  HF_STAMP(0);
 
   // S1: cat0 = [out_norm(x) | || pv0[:, :, :H] ||_s]
   for (int idx = tid; idx < M * H; idx += nthr) {
@@ -151,17 +233,21 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
     cat0[i * l2H + H + c] = sqrtf(s2);
   }
   __syncthreads();
+  HF_STAMP(1);
   // S2: a0 = cat0 . Wa0^T + ba0 ; ta = act(a0)
-  lds_gemm<1, 2 * H, H>(cat0, l2H, M, a.W.Wa0p, a.W.ba0, a0, lH, wave, lane);
+  lds_gemm8<2 * H, H>(cat0, l2H, M, a.W.Wa0p, a.W.ba0, a0, lH, wave, lane);
   __syncthreads();
+  HF_STAMP(2);
   for (int idx = tid; idx < M * H; idx += nthr) {
     const int i = idx / H, c = idx - i * H;
     ta[i * lH + c] = act_f(akind, a0[i * lH + c]);
   }
   __syncthreads();
+  HF_STAMP(3);
   // S3: u0 = ta . Wb0^T + bb0 = [xs | gate]
-  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0p, a.W.bb0, u0, lH, wave, lane);
+  lds_gemm8<H, H>(ta, lH, M, a.W.Wb0p, a.W.bb0, u0, lH, wave, lane);
   __syncthreads();
+  HF_STAMP(4);
   // S4: cat1[:, :h2] = act(xs) ; vec1o[s] = gate * pv0[s, H:]
   for (int idx = tid; idx < M * h2; idx += nthr) {
     const int i = idx / h2, c = idx - i * h2;
@@ -172,9 +258,11 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
       vec1o[(i * S + s) * lh + c] = gate * a.pv0[((size_t)(n0 + i) * S + s) * ldp + H + c];
   }
   __syncthreads();
+  HF_STAMP(5);
   // S5: p1 = vec1o . W11^T
   lds_gemm<RBV, h2, h2>(vec1o, lh, MR, a.W.W11p, nullptr, p1, lh, wave, lane);
   __syncthreads();
+  HF_STAMP(6);
   // S6: cat1[:, h2:] = || p1 ||_s
   for (int idx = tid; idx < M * h2; idx += nthr) {
     const int i = idx / h2, c = idx - i * h2;
@@ -187,9 +275,11 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
     cat1[i * lH + h2 + c] = sqrtf(s2);
   }
   __syncthreads();
+  HF_STAMP(7);
   // S7: a1b = cat1 . Wa1^T + ba1
-  lds_gemm<1, H, h2>(cat1, lH, M, a.W.Wa1p, a.W.ba1, a1b, lh, wave, lane);
+  lds_gemm8<H, h2>(cat1, lH, M, a.W.Wa1p, a.W.ba1, a1b, lh, wave, lane);
   __syncthreads();
+  HF_STAMP(8);
   // S8: y = std (wb1 . act(a1b) + bb1) + atomref[z] ; g_a1 = std wb1 act'(a1b)   (dE/dy = 1)
   if (wave < M) {
     const int i = wave;
@@ -208,9 +298,11 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
     }
   }
   __syncthreads();
+  HF_STAMP(9);
   // S10: g_cat1 = g_a1 . Wa1
-  lds_gemm<1, h2, H>(a1b, lh, M, a.W.Wa1Tp, nullptr, gcat1, lH, wave, lane);
+  lds_gemm8<h2, H>(a1b, lh, M, a.W.Wa1Tp, nullptr, gcat1, lH, wave, lane);
   __syncthreads();
+  HF_STAMP(10);
   // S11: g_p1[s] = g_v1b / v1b * p1[s]   (0 where v1b == 0, like torch.norm)
   for (int idx = tid; idx < M * h2; idx += nthr) {
     const int i = idx / h2, c = idx - i * h2;
@@ -220,9 +312,11 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
     for (int s = 0; s < S; ++s) p1[(i * S + s) * lh + c] *= sc;
   }
   __syncthreads();
+  HF_STAMP(11);
   // S12: g_vec1o = g_p1 . W11
   lds_gemm<RBV, h2, h2>(p1, lh, MR, a.W.W11Tp, nullptr, vec1o, lh, wave, lane);
   __syncthreads();
+  HF_STAMP(12);
   // S13: g_gate = sum_s g_vec1o[s] v2[s] ; g_v2[s] = g_vec1o[s] gate ; g_xs = g_x1 act'(xs)
   for (int idx = tid; idx < M * h2; idx += nthr) {
     const int i = idx / h2, c = idx - i * h2;
@@ -239,17 +333,21 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
     ta[i * lH + h2 + c] = gg;
   }
   __syncthreads();
+  HF_STAMP(13);
   // S14: g_h0 = (g_u0 . Wb0) * act'(a0)
-  lds_gemm<1, H, H>(ta, lH, M, a.W.Wb0Tp, nullptr, cat1, lH, wave, lane);
+  lds_gemm8<H, H>(ta, lH, M, a.W.Wb0Tp, nullptr, cat1, lH, wave, lane);
   __syncthreads();
+  HF_STAMP(14);
   for (int idx = tid; idx < M * H; idx += nthr) {
     const int i = idx / H, c = idx - i * H;
     cat1[i * lH + c] *= dact_f(akind, a0[i * lH + c]);
   }
   __syncthreads();
+  HF_STAMP(15);
   // S15: g_cat0 = g_h0 . Wa0
-  lds_gemm<1, H, 2 * H>(cat1, lH, M, a.W.Wa0Tp, nullptr, gcat0, l2H, wave, lane);
+  lds_gemm8<H, 2 * H>(cat1, lH, M, a.W.Wa0Tp, nullptr, gcat0, l2H, wave, lane);
   __syncthreads();
+  HF_STAMP(16);
   // S16: dE/d out_norm(x) -> global ; g_pv0[s, :H] = g_v1 / v1 * pv0[s, :H]
   for (int idx = tid; idx < M * H; idx += nthr) {
     const int i = idx / H, c = idx - i * H;
@@ -262,6 +360,7 @@ __global__ __launch_bounds__(64 * HF_WAVES) void hk_fused(HeadFusedArgs a) {
       a.g_pv0[pr] = sc * a.pv0[pr];
     }
   }
+  HF_STAMP(17);
 }
 
 static size_t head_fused_lds(int H, int S) {
@@ -330,3 +429,10 @@ int launch_head_fused(hipStream_t st, const Dims& D, const HeadW& W, const HeadB
 }
 
 }  // namespace vsn
+
+#ifdef HF_LAB_STAMPS
+extern "C" int vsn_lab_set_hf_stamps(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vsn::g_hf_stamps), &q, sizeof(q));
+}
+#endif
