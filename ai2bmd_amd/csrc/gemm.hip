@@ -458,6 +458,9 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
     VSN_TRY(14, 128, 64, 2, 2, false)
     VSN_TRY(15, 64, 64, 2, 2, true)
     VSN_TRY(16, 128, 128, 2, 2, false)
+    VSN_TRY(17, 256, 256, 2, 2, false)
+    VSN_TRY(18, 256, 128, 2, 2, false)
+    VSN_TRY(19, 128, 256, 2, 2, false)
 #undef VSN_TRY
   }
   if (flags & 2) {  // silu(A): its own instantiations, no split-K
