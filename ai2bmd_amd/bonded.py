@@ -164,6 +164,7 @@ class ShardedFragmentForces:
         self.direct = False  # True when local_fn writes straight into the exchange buffer
         self.emulate = False
         self.force_collective = False  # world == 1: still go through the all-gather (exercises RCCL on a 1-GPU box)
+        self.fused_tail = None
         self.energy_sign = torch.as_tensor(plan.energy_sign, device=device)
         nonempty = (plan.end - plan.start) > 0
         self._e_index = torch.as_tensor(
@@ -181,7 +182,18 @@ class ShardedFragmentForces:
 
     def step(self, prot_pos):
         """prot_pos [n_prot,3] on self.device -> (E 0-d tensor, F [n_prot,3] tensor)."""
-        e_loc, f_loc = self.local_fn(prot_pos)
+        buf = self.exchange(prot_pos)
+        if self.combine_energy_fn is not None:  # product wiring: forces and total energy in one HIP launch
+            return self.combine_energy_fn(buf)
+        F = self.combine_fn(buf)
+        E = (buf[self._e_index] * self._e_sign).sum()
+        return E, F
+
+    def exchange(self, prot_pos, prebuilt=False):
+        """Everything of `step` in front of the combine: this rank's fragments evaluated, every rank's forces and
+        energies gathered -> the padded buffer the combine reads.  prebuilt: the fragment geometry of `prot_pos` is
+        already in `self.frag_pos` (the integrator's fused first half wrote it: LangevinHIP, vsn_md_half1_build)."""
+        e_loc, f_loc = self.local_fn(prot_pos, prebuilt) if prebuilt else self.local_fn(prot_pos)
         stage = self.recv if (self.world == 1 and not self.force_collective) else self.send
         if not self.direct:  # local_fn returned its own tensors: stage them into the exchange buffer
             stage[: self.local_rows * 3] = f_loc.reshape(-1)
@@ -194,12 +206,7 @@ class ShardedFragmentForces:
             import torch.distributed as dist
 
             dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        buf = self.recv
-        if self.combine_energy_fn is not None:  # product wiring: forces and total energy in one HIP launch
-            return self.combine_energy_fn(buf)
-        F = self.combine_fn(buf)
-        E = (buf[self._e_index] * self._e_sign).sum()
-        return E, F
+        return self.recv
 
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
@@ -252,13 +259,14 @@ class ShardedFragmentForces:
         self.direct = True
         F_prot = torch.empty(plan.n_prot, 3, dtype=torch.float32, device=dev)
 
-        def local_fn(prot_pos):
+        def local_fn(prot_pos, prebuilt=False):
             st = torch.cuda.current_stream(dev)
             if nloc:
-                rc_ = L.vsn_build_fragments(self._fp, C.c_void_p(prot_pos.data_ptr()),
-                                            C.c_void_p(pos_geo.data_ptr()), C.c_void_p(st.cuda_stream))
-                if rc_:
-                    raise RuntimeError(f"vsn_build_fragments failed ({rc_})")
+                if not prebuilt:
+                    rc_ = L.vsn_build_fragments(self._fp, C.c_void_p(prot_pos.data_ptr()),
+                                                C.c_void_p(pos_geo.data_ptr()), C.c_void_p(st.cuda_stream))
+                    if rc_:
+                        raise RuntimeError(f"vsn_build_fragments failed ({rc_})")
                 if self.relaxer is not None:
                     self.relaxer.run(pos_geo, st)
                 engine.forces_device(z_loc[:nloc], pos_loc[:nloc], self.local_start, self.local_end, e_loc[:bloc],
@@ -290,5 +298,7 @@ class ShardedFragmentForces:
             return E_tot[0], F_prot
 
         self.local_fn, self.combine_fn, self.combine_energy_fn = local_fn, combine_fn, combine_energy_fn
+        # what the integrator's fused halves need (LangevinHIP: vsn_md_half1_build / vsn_md_combine_half2)
+        self.fused_tail = (self._fp, self._cp, pos_geo, F_prot, E_tot) if nloc else None
         self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot, E_tot)
         return self

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvsn_hip.so")
 SOURCES = ["gemm.hip", "graph.hip", "layer_fwd.hip", "layer_bwd.hip", "fused.hip", "vecnorm.hip", "head.hip", "head_fused.hip", "md.hip", "mm.hip", "hydrogen.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", "pgemm.h", os.path.join("..", "..", "include", "vsn.h")]
+HEADERS = ["common.h", "kernels.h", "pgemm.h", "tail.h", os.path.join("..", "..", "include", "vsn.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -19,6 +19,7 @@
 #include "../../include/vsn.h"
 #include "kernels.h"
 #include "pgemm.h"
+#include "tail.h"
 
 using namespace vsn;
 
@@ -1092,7 +1093,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   RC(launch_gemm(st, c->g_x, H, c->WcnT, H, c->g_n, H, nullptr, N, nullptr, H, H, 0));
   RC(launch_bwd_embed_node(st, D, c->emb2, c->pp, c->g_n, c->g_pp, c->g_geo));
   RC(launch_gemm(st, c->g_pp, 2 * H, c->WrbfT, 2 * H, c->g_rbf, Rp, nullptr, Emax, EP, Rp, 2 * H, 0));
-  RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out));
+  RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out, c->debug));
 #undef RC
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(c, -5, std::string("kernel launch error: ") + hipGetErrorString(le));
@@ -1511,6 +1512,18 @@ extern "C" int vsn_build_fragments(vsn_fragplan_handle p, const float* prot, flo
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   launch_build_fragments((hipStream_t)stream, p->n, p->src, p->acc, p->tow, p->len, prot, out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+// device views of the two plans for the launches fused with the integrator halves (md.hip)
+int vsn_combine_plan_view(vsn_combine_plan* p, vsn::CombineView* out) {
+  if (!p || !out) return -22;
+  *out = vsn::CombineView{p->device, p->n_prot, p->n_e, p->off, p->rows, p->e_idx, p->sign, p->e_sign};
+  return 0;
+}
+int vsn_fragplan_view(vsn_fragplan* p, vsn::FragView* out) {
+  if (!p || !out) return -22;
+  *out = vsn::FragView{p->device, p->n, p->src, p->acc, p->tow, p->len};
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------

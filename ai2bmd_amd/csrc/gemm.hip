@@ -385,6 +385,7 @@ __global__ void k_gemm_reduce_group(GemmGroup g) {
 
 // ---- optional per-launch timing (bench.py roofline leg): HIP events on the launch stream ----
 int g_splitk_tiles = 400;   // split-K only below this many output tiles (env VSN_SPLITK_TILES; swept on Chignolin: 0:297, 200:306, 400:306, 768:301, 1200:289 steps/s)
+int g_splitk_mink = 512;  // plain launches: split-K from this K on (env VSN_SPLITK_MINK, A/B aid)
 int g_gemm_force = 0;     // micro-benchmark aid (env VSN_GEMM_FORCE): force an experimental tile variant
 int g_gemm_db128 = 0;  // A/B switch (env VSN_GEMM_DB128): measured 3-6 % slower than single-buffered at 128x128
 static thread_local GemmProfiler* tl_prof = nullptr;
@@ -404,6 +405,8 @@ static bool gemm_env_init() {
   if (e) g_gemm_db128 = atoi(e);
   e = getenv("VSN_SPLITK_TILES");
   if (e) g_splitk_tiles = atoi(e);
+  e = getenv("VSN_SPLITK_MINK");
+  if (e) g_splitk_mink = atoi(e);
   e = getenv("VSN_GEMM_FORCE");
   if (e) g_gemm_force = atoi(e);
   return true;
@@ -486,7 +489,7 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   // split-K: few output tiles and a long K (the dX = dY.W products of the reverse pass on small
   // batches) would leave most CUs idle; cut K over `ks` workgroups and reduce deterministically.
   int ks = 1;
-  if (tiles < g_splitk_tiles && K >= 512 && tl_splitk_ws && (ldc & 3) == 0) {
+  if (tiles < g_splitk_tiles && K >= g_splitk_mink && tl_splitk_ws && (ldc & 3) == 0) {
     ks = (1024 + tiles - 1) / tiles;
     const int kmax = K / 128;  // keep >= 4 k-tiles per split
     if (ks > kmax) ks = kmax;

@@ -316,14 +316,11 @@ __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict
 
 // reverse of the geometry: dE/d(edge vector) per edge from the accumulated
 // dE/dr-ish terms (g_rbf . drbf + g_C * dC) and dE/dd (through the SH Jacobian
-// and the unit-vector normalisation).  one thread per edge.
-__global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restrict__ geo,
-                           const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
-                           const float* __restrict__ g_geo /*[E,32]: g_d 0..7, 16..23 and 24..31, g_C at 8*/, int S,
-                           float* __restrict__ g_ev /*[E,4]*/) {
-  const int E = *ecount;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
+// and the unit-vector normalisation).
+__device__ __forceinline__ void edge_force(int e, const float* __restrict__ geo, const float* __restrict__ g_rbf,
+                                           const float* __restrict__ drbf, int Rp,
+                                           const float* __restrict__ g_geo /*[E,32]: g_d 0..7, 16..23 and 24..31, g_C at 8*/,
+                                           int S, float& ox, float& oy, float& oz) {
   const float* g = geo + (size_t)e * 8;
   const float dC = g[2], ux = g[3], uy = g[4], uz = g[5], rinv = g[6];
   float gr = g_geo[(size_t)e * VSN_GEO_W + 8] * dC;
@@ -350,10 +347,21 @@ __global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restri
     gz += s3 * ux * gd[3] - uz * gd[5] + s3 * uy * gd[6] + s3 * uz * gd[7];
   }
   float dot = gx * ux + gy * uy + gz * uz;
-  float ox = gr * ux + (gx - dot * ux) * rinv;
-  float oy = gr * uy + (gy - dot * uy) * rinv;
-  float oz = gr * uz + (gz - dot * uz) * rinv;
+  ox = gr * ux + (gx - dot * ux) * rinv;
+  oy = gr * uy + (gy - dot * uy) * rinv;
+  oz = gr * uz + (gz - dot * uz) * rinv;
   if (rinv == 0.f) ox = oy = oz = 0.f;  // self loop: no position dependence
+}
+
+// one thread per edge -> g_ev [E,4]
+__global__ void k_bwd_geom(const int* __restrict__ ecount, const float* __restrict__ geo,
+                           const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
+                           const float* __restrict__ g_geo, int S, float* __restrict__ g_ev /*[E,4]*/) {
+  const int E = *ecount;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  float ox, oy, oz;
+  edge_force(e, geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
   float* o = g_ev + (size_t)e * 4;
   o[0] = ox;
   o[1] = oy;
@@ -380,6 +388,44 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
       fx -= g_ev[4 * (size_t)e + 0];
       fy -= g_ev[4 * (size_t)e + 1];
       fz -= g_ev[4 * (size_t)e + 2];
+    }
+  }
+  fx = group_sum(fx, 16);
+  fy = group_sum(fy, 16);
+  fz = group_sum(fz, 16);
+  if (*status == epoch) fx = fy = fz = __builtin_nanf("");  // invalid input (atomic number out of range): fail loudly
+  if (live && l == 0) {
+    f_out[3 * (size_t)i + 0] = fx;
+    f_out[3 * (size_t)i + 1] = fy;
+    f_out[3 * (size_t)i + 2] = fz;
+  }
+}
+
+// Single-protein sizes: the two passes above in ONE launch - every lane evaluates the edge vector's adjoint of the
+// edges it sums (each edge twice: once at its target, once at its source; a few hundred bytes of L2-resident rows),
+// g_ev never exists.  Same per-edge arithmetic and the same summation order as k_bwd_geom + k_force_gather.
+__global__ void k_force_gather_geom(int N, const int* __restrict__ rowptr, const int* __restrict__ colptr,
+                                    const int* __restrict__ perm, const float* __restrict__ geo,
+                                    const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
+                                    const float* __restrict__ g_geo, int S, float* __restrict__ f_out,
+                                    const int* __restrict__ status, int epoch) {
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
+  const bool live = i < N;
+  float fx = 0.f, fy = 0.f, fz = 0.f;
+  if (live) {
+    for (int e = rowptr[i] + l; e < rowptr[i + 1]; e += 16) {
+      float ox, oy, oz;
+      edge_force(e, geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
+      fx += ox;
+      fy += oy;
+      fz += oz;
+    }
+    for (int t = colptr[i] + l; t < colptr[i + 1]; t += 16) {
+      float ox, oy, oz;
+      edge_force(perm[t], geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
+      fx -= ox;
+      fy -= oy;
+      fz -= oz;
     }
   }
   fx = group_sum(fx, 16);
@@ -430,8 +476,13 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
 }
 
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
-                    float* f_out) {
+                    float* f_out, bool keep_g_ev) {
   if (a.N <= 0) return 0;
+  if (a.N < 4096 && !keep_g_ev) {  // single-protein sizes: one launch, g_ev is not materialised
+    hipLaunchKernelGGL(k_force_gather_geom, dim3((a.N + 15) / 16), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
+                       a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S, f_out, a.status, a.epoch);
+    return 0;
+  }
   int blocks = (a.Emax + 255) / 256;
   if (blocks > 0)
     hipLaunchKernelGGL(k_bwd_geom, dim3(blocks), dim3(256), 0, st, a.ecount, a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S,

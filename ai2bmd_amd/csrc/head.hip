@@ -8,6 +8,7 @@
 // elementwise glue here is N-sized (negligible next to the E-sized layer work).
 #include "common.h"
 #include "kernels.h"
+#include "tail.h"
 
 namespace vsn {
 
@@ -183,21 +184,13 @@ __global__ void k_combine(int n_prot, const int* __restrict__ off, const int* __
                           float* __restrict__ f_prot, int n_e, const int* __restrict__ e_idx,
                           const float* __restrict__ e_sign, float* __restrict__ e_out) {
   if (e_out && blockIdx.x == 0 && threadIdx.x < 64) {
-    float s = 0.f;
-    for (int k = threadIdx.x; k < n_e; k += 64) s += e_sign[k] * f_frag[e_idx[k]];
-    s = wave_sum(s);
+    const float s = combine_energy_wave((int)threadIdx.x, n_e, e_idx, e_sign, f_frag);
     if (threadIdx.x == 0) *e_out = s;
   }
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_prot) return;
-  float fx = 0.f, fy = 0.f, fz = 0.f;
-  for (int k = off[a]; k < off[a + 1]; ++k) {
-    const float s = sign[k];
-    const size_t r = (size_t)rows[k] * 3;
-    fx += s * f_frag[r + 0];
-    fy += s * f_frag[r + 1];
-    fz += s * f_frag[r + 2];
-  }
+  float fx, fy, fz;
+  combine_atom(a, off, rows, sign, f_frag, fx, fy, fz);
   f_prot[3 * (size_t)a + 0] = fx;
   f_prot[3 * (size_t)a + 1] = fy;
   f_prot[3 * (size_t)a + 2] = fz;
@@ -217,24 +210,7 @@ __global__ void k_build_fragments(int n, const int* __restrict__ src, const int*
                                   const float* __restrict__ prot, float* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
-  const int s = src[k];
-  float x, y, z;
-  if (s >= 0) {
-    x = prot[3 * (size_t)s + 0];
-    y = prot[3 * (size_t)s + 1];
-    z = prot[3 * (size_t)s + 2];
-  } else {
-    const int a = acc[k], t = tow[k];
-    const float ax = prot[3 * (size_t)a + 0], ay = prot[3 * (size_t)a + 1], az = prot[3 * (size_t)a + 2];
-    float dx = prot[3 * (size_t)t + 0] - ax, dy = prot[3 * (size_t)t + 1] - ay, dz = prot[3 * (size_t)t + 2] - az;
-    const float sc = len[k] / sqrtf(dx * dx + dy * dy + dz * dz);
-    x = ax + dx * sc;
-    y = ay + dy * sc;
-    z = az + dz * sc;
-  }
-  out[3 * (size_t)k + 0] = x;
-  out[3 * (size_t)k + 1] = y;
-  out[3 * (size_t)k + 2] = z;
+  build_row(k, src, acc, tow, len, prot, out);
 }
 
 int launch_build_fragments(hipStream_t st, int n, const int* src, const int* acc, const int* tow, const float* len,

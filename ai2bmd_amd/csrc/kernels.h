@@ -119,8 +119,9 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n);
 bool gemm_group_ok(const GemmDesc* descs, int n);
 
 int launch_graph(hipStream_t st, const GraphArgs& a);
+// keep_g_ev: the debug tap wants the per-edge adjoint in HBM; otherwise single-protein sizes fold it into the gather
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
-                    float* f_out);
+                    float* f_out, bool keep_g_ev);
 
 // ---- forward ----
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,

@@ -25,6 +25,7 @@
 
 #include "../../include/vsn.h"
 #include "common.h"
+#include "tail.h"
 
 namespace vsn {
 
@@ -70,12 +71,12 @@ __device__ __forceinline__ void normals6(unsigned long long seed, unsigned step,
 }
 
 // single workgroup (proteins here have a few hundred to a few thousand atoms)
-__global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restrict__ mass,
-                                                   const float* __restrict__ c3, const float* __restrict__ c4,
-                                                   const float* __restrict__ c5, float c1, float c2, float dt,
-                                                   unsigned long long seed, unsigned step, float* __restrict__ x,
-                                                   float* __restrict__ v, const float* __restrict__ F,
-                                                   float* __restrict__ rnd_vel) {
+__device__ __forceinline__ void md_half1_body(int n, const float* __restrict__ mass, const float* __restrict__ c3,
+                                              const float* __restrict__ c4, const float* __restrict__ c5, float c1,
+                                              float c2, float dt, unsigned long long seed, unsigned step,
+                                              float* __restrict__ x, float* __restrict__ v,
+                                              const float* __restrict__ F, float* __restrict__ rnd_vel) {
+#pragma clang fp contract(off)
   __shared__ float red[6][16];
   __shared__ float tot[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,6 +124,30 @@ __global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restric
   }
 }
 
+__global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restrict__ mass,
+                                                   const float* __restrict__ c3, const float* __restrict__ c4,
+                                                   const float* __restrict__ c5, float c1, float c2, float dt,
+                                                   unsigned long long seed, unsigned step, float* __restrict__ x,
+                                                   float* __restrict__ v, const float* __restrict__ F,
+                                                   float* __restrict__ rnd_vel) {
+  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel);
+}
+
+// half1 + the fragment-geometry gather of the NEW positions (the first kernel of the force evaluation that follows:
+// vsn_build_fragments), one launch: the workgroup's own position writes are visible to it after the barrier
+__global__ __launch_bounds__(1024) void k_md_half1_build(int n, const float* __restrict__ mass,
+                                                         const float* __restrict__ c3, const float* __restrict__ c4,
+                                                         const float* __restrict__ c5, float c1, float c2, float dt,
+                                                         unsigned long long seed, unsigned step,
+                                                         float* __restrict__ x, float* __restrict__ v,
+                                                         const float* __restrict__ F, float* __restrict__ rnd_vel,
+                                                         FragView fp, float* __restrict__ frag_pos) {
+  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel);
+  __syncthreads();
+  const float* xn = x;  // (x is written above: no __restrict__ promise on this read)
+  for (int k = threadIdx.x; k < fp.n; k += blockDim.x) build_row(k, fp.src, fp.acc, fp.tow, fp.len, xn, frag_pos);
+}
+
 // One spring of an atom's list: towards a fixed point (partner < 0) or towards atom `partner`.
 struct Spring {
   int partner;
@@ -133,6 +158,7 @@ struct Spring {
 // ends and gives half its energy to each)
 __device__ __forceinline__ void restraint_of(int i, const float* __restrict__ x, const int* __restrict__ ptr,
                                              const Spring* __restrict__ sp, float (&f)[3], float& e) {
+#pragma clang fp contract(off)
   f[0] = f[1] = f[2] = 0.f;
   e = 0.f;
   const float xi = x[3 * (size_t)i], yi = x[3 * (size_t)i + 1], zi = x[3 * (size_t)i + 2];
@@ -165,24 +191,54 @@ __global__ void k_md_restrain(int n, const float* __restrict__ x, float* __restr
   e_r[i] = e;
 }
 
-// second half of the step, one thread per atom: restraints at the new positions are added INTO F, then
-// v += c1 F/m - c2 v + rnd_vel
-__global__ void k_md_half2(int n, const float* __restrict__ mass, float c1, float c2, const float* __restrict__ x,
-                           float* __restrict__ v, float* __restrict__ F, const float* __restrict__ rnd_vel,
-                           const int* __restrict__ ptr, const Spring* __restrict__ sp, float* __restrict__ e_r) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// second half of the step for atom i, model force fm: restraints at the new positions are added (the sum is what the
+// caller stores as F), then v += c1 F/m - c2 v + rnd_vel.  One statement of the arithmetic for the stand-alone and
+// the fused kernel, contraction pinned (explicit fmaf only), so that both round identically.
+__device__ __forceinline__ void md_half2_atom(int i, const float (&fm)[3], const float* __restrict__ mass, float c1,
+                                              float c2, const float* __restrict__ x, float* __restrict__ v,
+                                              float* __restrict__ F, bool store_f, const float* __restrict__ rnd_vel,
+                                              const int* __restrict__ ptr, const Spring* __restrict__ sp,
+                                              float* __restrict__ e_r) {
+#pragma clang fp contract(off)
   float fr[3] = {0.f, 0.f, 0.f}, e = 0.f;
   if (ptr) restraint_of(i, x, ptr, sp, fr, e);
   const float m = mass[i];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const size_t a = 3 * (size_t)i + k;
-    const float f = F[a] + fr[k];
-    if (ptr) F[a] = f;
-    v[a] = v[a] + (c1 * f / m - c2 * v[a] + rnd_vel[a]);
+    const float f = fm[k] + fr[k];
+    if (store_f) F[a] = f;
+    const float vo = v[a];
+    v[a] = vo + (fmaf(-c2, vo, c1 * f / m) + rnd_vel[a]);
   }
   if (ptr) e_r[i] = e;
+}
+
+__global__ void k_md_half2(int n, const float* __restrict__ mass, float c1, float c2, const float* __restrict__ x,
+                           float* __restrict__ v, float* __restrict__ F, const float* __restrict__ rnd_vel,
+                           const int* __restrict__ ptr, const Spring* __restrict__ sp, float* __restrict__ e_r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float fm[3] = {F[3 * (size_t)i], F[3 * (size_t)i + 1], F[3 * (size_t)i + 2]};
+  md_half2_atom(i, fm, mass, c1, c2, x, v, F, ptr != nullptr, rnd_vel, ptr, sp, e_r);
+}
+
+// the combine of the force evaluation (fragment rows -> protein atoms, total energy; vsn_combine_with_energy) + half2,
+// one launch: atom a's thread sums its fragment rows, writes F (model) and goes on as k_md_half2 does
+__global__ void k_md_combine_half2(int n, const float* __restrict__ mass, float c1, float c2,
+                                   const float* __restrict__ x, float* __restrict__ v, float* __restrict__ F,
+                                   const float* __restrict__ rnd_vel, const int* __restrict__ ptr,
+                                   const Spring* __restrict__ sp, float* __restrict__ e_r, CombineView cp,
+                                   const float* __restrict__ buf, float* __restrict__ e_out) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    const float s = combine_energy_wave((int)threadIdx.x, cp.n_e, cp.e_idx, cp.e_sign, buf);
+    if (threadIdx.x == 0) *e_out = s;
+  }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float fm[3];
+  combine_atom(i, cp.off, cp.rows, cp.sign, buf, fm[0], fm[1], fm[2]);
+  md_half2_atom(i, fm, mass, c1, c2, x, v, F, true, rnd_vel, ptr, sp, e_r);
 }
 
 // observables without leaving HBM: out[0] = kinetic energy sum m v^2 / 2, out[1] = restraint energy,
@@ -328,6 +384,30 @@ extern "C" int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, f
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   hipLaunchKernelGGL(vsn::k_md_half2, dim3((p->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->n, p->mass,
                      p->c1, p->c2, dev_x, dev_v, dev_F, p->rnd_vel, p->sp_ptr, p->sp, p->e_r);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_half1_build(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F,
+                                  vsn_fragplan_handle plan, float* dev_frag_pos, void* stream) {
+  if (!p || !plan || !dev_frag_pos) return -22;
+  vsn::FragView fv;
+  if (vsn_fragplan_view(plan, &fv) || fv.device != p->device) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  hipLaunchKernelGGL(vsn::k_md_half1_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->n, p->mass, p->c3, p->c4,
+                     p->c5, p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel, fv, dev_frag_pos);
+  p->step++;
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_combine_half2(vsn_md_handle p, vsn_combine_handle plan, const float* dev_buf, float* dev_F,
+                                    float* dev_e_out, const float* dev_x, float* dev_v, void* stream) {
+  if (!p || !plan || !dev_buf || !dev_F || !dev_e_out) return -22;
+  vsn::CombineView cv;
+  if (vsn_combine_plan_view(plan, &cv) || cv.device != p->device || cv.n_prot != p->n || cv.n_e <= 0) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  hipLaunchKernelGGL(vsn::k_md_combine_half2, dim3((p->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->n,
+                     p->mass, p->c1, p->c2, dev_x, dev_v, dev_F, p->rnd_vel, p->sp_ptr, p->sp, p->e_r, cv, dev_buf,
+                     dev_e_out);
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -192,10 +194,15 @@ class LangevinHIP(_MDBase):
     In-place contract (`inplace_forces=True`, the default): half2 ADDS the restraint forces into the tensor
     `force_fn` returned, so `force_fn` must hand back a buffer it rewrites on every call (the calculators of this
     package do).  A `force_fn` that returns a cached / constant tensor, or keeps using its result, needs
-    `inplace_forces=False`: the integrator then works on its own copy (one extra copy kernel per step)."""
+    `inplace_forces=False`: the integrator then works on its own copy (one extra copy kernel per step).
+
+    Fused ends (`fuse_tail=True`, the default): when `force_fn` is the `step` of a `ShardedFragmentForces` wired to the
+    HIP engine, the first half also gathers the fragment geometry of the new positions and the second half also
+    combines the fragment forces (`vsn_md_half1_build`, `vsn_md_combine_half2`): the same arithmetic in the same order
+    - bitwise the same trajectory - in two launches fewer per step.  Any other `force_fn` is called as is."""
 
     def __init__(self, numbers, positions, force_fn, device, timestep_fs=1.0, temperature_K=300.0,
-                 friction_per_fs=0.001, seed=0, tether_k=0.0, inplace_forces=True):
+                 friction_per_fs=0.001, seed=0, tether_k=0.0, inplace_forces=True, fuse_tail=True):
         import ctypes as C
 
         from . import capi
@@ -209,6 +216,12 @@ class LangevinHIP(_MDBase):
         self.x = torch.as_tensor(x0, device=device).contiguous()
         self.force_fn = force_fn
         self.inplace_forces = bool(inplace_forces)
+        ff = getattr(force_fn, "__self__", None)
+        tail = getattr(ff, "fused_tail", None)
+        fuse_tail = fuse_tail and os.environ.get("VSN_MD_FUSE", "1") != "0"  # A/B switch
+        self._ff = ff if (fuse_tail and inplace_forces and tail is not None and hasattr(ff, "exchange")
+                          and getattr(force_fn, "__name__", "") == "step" and tail[3].shape[0] == self.n
+                          and tail[3].device == torch.device(device)) else None
         self.tether_k = float(tether_k)
         self._x0 = x0.astype(np.float64)
         self.constraints = []
@@ -271,7 +284,27 @@ class LangevinHIP(_MDBase):
             raise RuntimeError(f"vsn_md_set_restraints failed ({rc})")
         self._start_forces()  # forces of the current geometry under the new restraint set
 
+    def _step_fused(self):
+        """half1 + fragment gather | local evaluation + exchange | combine + half2"""
+        C = self._C
+        st = self._stream()
+        fp, cp, frag_pos, F_prot, E_tot = self._ff.fused_tail
+        rc = self._L.vsn_md_half1_build(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                        C.c_void_p(self.F.data_ptr()), fp, C.c_void_p(frag_pos.data_ptr()), st)
+        if rc:
+            raise RuntimeError(f"vsn_md_half1_build failed ({rc})")
+        buf = self._ff.exchange(self.x, prebuilt=True)
+        rc = self._L.vsn_md_combine_half2(self._h, cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
+                                          C.c_void_p(E_tot.data_ptr()), C.c_void_p(self.x.data_ptr()),
+                                          C.c_void_p(self.v.data_ptr()), st)
+        if rc:
+            raise RuntimeError(f"vsn_md_combine_half2 failed ({rc})")
+        self.E_model, self.F = E_tot[0], F_prot
+        self.steps += 1
+
     def step(self):
+        if self._ff is not None:
+            return self._step_fused()
         C = self._C
         st = self._stream()
         rc = self._L.vsn_md_half1(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),

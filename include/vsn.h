@@ -172,6 +172,17 @@ int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n_atoms, const floa
 void vsn_md_destroy(vsn_md_handle p);
 int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, void* stream);
 int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, float* dev_F, void* stream);
+/* The same two halves with the neighbouring launch of the force evaluation folded in (same arithmetic, same order,
+ * bitwise the same trajectory; two launches fewer per step):
+ *   vsn_md_half1_build    = vsn_md_half1, then vsn_build_fragments(plan) of the NEW positions into dev_frag_pos
+ *                           (the gather DistanceFragment.get_fragments starts with, distancefrag.py:35-54);
+ *   vsn_md_combine_half2  = vsn_combine_with_energy(plan) of the (all-gathered) fragment buffer dev_buf into dev_F
+ *                           [n_atoms,3] and dev_e_out [1] (combiner.py:12-41), then vsn_md_half2 on that dev_F.
+ * The plans must live on the integrator's device; the combine plan needs its energy terms set and n_prot = n_atoms. */
+int vsn_md_half1_build(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, vsn_fragplan_handle plan,
+                       float* dev_frag_pos, void* stream);
+int vsn_md_combine_half2(vsn_md_handle p, vsn_combine_handle plan, const float* dev_buf, float* dev_F,
+                         float* dev_e_out, const float* dev_x, float* dev_v, void* stream);
 /* Replaces the restraint set (synchronises the device).  Point springs: atom[t] towards origin3[3t..], force
  * k (r - rt) along the line when r > rt, energy k (r - rt)^2 / 2 - `Hookean(a1=idx, a2=pos, k, rt)`, the
  * pre-equilibration stages (simulator.py:139-166).  Pair springs between atoms a1[t], a2[t] - `Hookean(a1, a2, k, rt)`,

@@ -95,6 +95,48 @@ def test_short_md_is_finite_and_reproducible(setup):
     assert np.abs(x1 - prot.positions).max() < 1.0  # tethered: stays near the start geometry
 
 
+@pytest.mark.parametrize("relax,collective", [(False, False), (True, False), (True, True)])
+def test_fused_integrator_ends_give_the_same_trajectory_bit_for_bit(setup, relax, collective):
+    """LangevinHIP folds the fragment gather into its first half and the combine into its second
+    (vsn_md_half1_build / vsn_md_combine_half2) when it drives a ShardedFragmentForces: two launches fewer, the same
+    arithmetic in the same order - positions, velocities, forces, energies and observables equal bit for bit to the
+    unfused sequence, with and without the cap-hydrogen relaxation and through the (one-rank) all-gather."""
+    import torch.distributed as dist
+
+    from ai2bmd_amd.amber import load_tables
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+    from ai2bmd_amd.hydrogen import build_hydrogen_plan
+    from ai2bmd_amd.md import Hookean, LangevinHIP
+
+    hp, sd, prot, plan, model = setup
+    hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(GOLDEN, "amber_tables.npz"))) if relax else None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29534")
+    created = collective and not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    out = {}
+    try:
+        for fuse in (True, False):
+            ff = ShardedFragmentForces.for_engine(model.engine, plan, hydrogen=hplan, force_collective=collective)
+            md = LangevinHIP(prot.numbers, prot.positions, ff.step, "cuda:0", seed=11, tether_k=2.0, fuse_tail=fuse)
+            assert (md._ff is not None) == fuse
+            md.set_constraints([Hookean(0, 5, 3.0, rt=1.0)])
+            rec = []
+            for _ in range(12):
+                md.step()
+                rec.append((md.x.cpu().numpy().copy(), md.v.cpu().numpy().copy(), md.F.cpu().numpy().copy(),
+                            float(md.E_model), md.observe()))
+            out[fuse] = rec
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for a, b in zip(out[True], out[False]):
+        for u, w in zip(a[:3], b[:3]):
+            assert np.isfinite(u).all() and np.array_equal(u, w)
+        assert a[3] == b[3] and a[4] == b[4]
+
+
 def test_two_handles_driven_from_two_threads(setup):
     """DLBondedCalculator drives one model per device from a thread pool (bonded.py:75-77).  Two handles on
     the same GPU stand in for two devices: partitions are evaluated concurrently and concatenated."""
