@@ -401,38 +401,36 @@ __global__ void k_force_gather(int N, const int* __restrict__ rowptr, const int*
   }
 }
 
-// Single-protein sizes: the two passes above in ONE launch - every lane evaluates the edge vector's adjoint of the
-// edges it sums (each edge twice: once at its target, once at its source; a few hundred bytes of L2-resident rows),
-// g_ev never exists.  Same per-edge arithmetic and the same summation order as k_bwd_geom + k_force_gather.
-__global__ void k_force_gather_geom(int N, const int* __restrict__ rowptr, const int* __restrict__ colptr,
-                                    const int* __restrict__ perm, const float* __restrict__ geo,
-                                    const float* __restrict__ g_rbf, const float* __restrict__ drbf, int Rp,
-                                    const float* __restrict__ g_geo, int S, float* __restrict__ f_out,
-                                    const int* __restrict__ status, int epoch) {
-  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4), l = threadIdx.x & 15;
-  const bool live = i < N;
+// Single-protein sizes: the two passes above in ONE launch - a WAVE per atom, one lane per incident edge (in-edges,
+// then out-edges through perm), every lane evaluates the adjoint of its edge vector itself (each edge twice: once at
+// its target, once at its source; a few hundred bytes of L2-resident rows) and the wave adds the contributions up;
+// g_ev never exists.  (The dependent chain rowptr -> edge -> rows is walked ONCE per lane: 16 lanes per atom walking
+// two or three edges each took 14 us, longer than the two launches it replaced.)
+__global__ __launch_bounds__(256) void k_force_gather_geom(int N, const int* __restrict__ rowptr,
+                                                           const int* __restrict__ colptr, const int* __restrict__ perm,
+                                                           const float* __restrict__ geo, const float* __restrict__ g_rbf,
+                                                           const float* __restrict__ drbf, int Rp,
+                                                           const float* __restrict__ g_geo, int S,
+                                                           float* __restrict__ f_out, const int* __restrict__ status,
+                                                           int epoch) {
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), l = threadIdx.x & 63;
+  if (i >= N) return;  // (wave-uniform)
+  const int r0 = rowptr[i], din = rowptr[i + 1] - r0, c0 = colptr[i], tot = din + colptr[i + 1] - c0;
   float fx = 0.f, fy = 0.f, fz = 0.f;
-  if (live) {
-    for (int e = rowptr[i] + l; e < rowptr[i + 1]; e += 16) {
-      float ox, oy, oz;
-      edge_force(e, geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
-      fx += ox;
-      fy += oy;
-      fz += oz;
-    }
-    for (int t = colptr[i] + l; t < colptr[i + 1]; t += 16) {
-      float ox, oy, oz;
-      edge_force(perm[t], geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
-      fx -= ox;
-      fy -= oy;
-      fz -= oz;
-    }
+  for (int t = l; t < tot; t += 64) {
+    const bool in = t < din;
+    const int e = in ? r0 + t : perm[c0 + t - din];
+    float ox, oy, oz;
+    edge_force(e, geo, g_rbf, drbf, Rp, g_geo, S, ox, oy, oz);
+    fx += in ? ox : -ox;
+    fy += in ? oy : -oy;
+    fz += in ? oz : -oz;
   }
-  fx = group_sum(fx, 16);
-  fy = group_sum(fy, 16);
-  fz = group_sum(fz, 16);
+  fx = wave_sum(fx);
+  fy = wave_sum(fy);
+  fz = wave_sum(fz);
   if (*status == epoch) fx = fy = fz = __builtin_nanf("");  // invalid input (atomic number out of range): fail loudly
-  if (live && l == 0) {
+  if (l == 0) {
     f_out[3 * (size_t)i + 0] = fx;
     f_out[3 * (size_t)i + 1] = fy;
     f_out[3 * (size_t)i + 2] = fz;
@@ -479,7 +477,7 @@ int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, cons
                     float* f_out, bool keep_g_ev) {
   if (a.N <= 0) return 0;
   if (a.N < 4096 && !keep_g_ev) {  // single-protein sizes: one launch, g_ev is not materialised
-    hipLaunchKernelGGL(k_force_gather_geom, dim3((a.N + 15) / 16), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
+    hipLaunchKernelGGL(k_force_gather_geom, dim3((a.N + 3) / 4), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
                        a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S, f_out, a.status, a.epoch);
     return 0;
   }

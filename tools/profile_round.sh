@@ -17,7 +17,7 @@ for W in chig batch; do
   python "$R/tools/rocpd_stats.py" "$DB" > "$OUT/${W}_kernel_stats.csv"
   python "$R/tools/rocpd_stats.py" "$DB" --busy 0.3 0.6 > "$OUT/${W}_busy.txt"
   # one step of the TIMED region as a kernel sequence (the last five steps of a bench run are the instrumented pass)
-  [ "$W" = chig ] && python "$R/tools/rocpd_stats.py" "$DB" --timeline k_build_fragments -20 > "$OUT/chig_step_timeline.csv"
+  [ "$W" = chig ] && python "$R/tools/rocpd_stats.py" "$DB" --timeline k_md_half1_build -20 > "$OUT/chig_step_timeline.csv"
   rm -rf "$OUT/kt_$W"
 done
 i=0
