@@ -811,6 +811,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   g.g_geo = c->g_geo;
   c->hw.epoch = c->epoch;
   c->hw.fuse = (c->fuse_head && !c->debug) ? 1 : 0;
+  c->hw.defer_energy = c->debug ? 0 : 1;  // (the debug build of the step keeps g_ev and the two-launch force fold)
   g.z_limit = c->hw.atomref ? std::min(c->Z, c->n_atomref) : c->Z;
   c->hw.status = c->status;
   g.geo = c->geo;
@@ -1093,7 +1094,11 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   RC(launch_gemm(st, c->g_x, H, c->WcnT, H, c->g_n, H, nullptr, N, nullptr, H, H, 0));
   RC(launch_bwd_embed_node(st, D, c->emb2, c->pp, c->g_n, c->g_pp, c->g_geo));
   RC(launch_gemm(st, c->g_pp, 2 * H, c->WrbfT, 2 * H, c->g_rbf, Rp, nullptr, Emax, EP, Rp, 2 * H, 0));
-  RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out, c->debug));
+  {
+    EnergyFold ef{0, nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (head_defers_energy(D, c->hw)) ef = EnergyFold{Bn, c->fstart, c->fend, c->hb.y, c->hw.mean, e_out};
+    RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out, c->debug, ef));
+  }
 #undef RC
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(c, -5, std::string("kernel launch error: ") + hipGetErrorString(le));

@@ -11,6 +11,8 @@
 // by source (perm/colptr) for the reverse pass' deterministic segmented sums.
 // Fragments of AI2BMD are tiny (<= 44 atoms): one workgroup per fragment, everything in LDS.  Batches holding a
 // larger fragment (whole-molecule mode, B = 1, up to VSN_MAX_FRAG_ATOMS) take the node-parallel passes below.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -412,8 +414,14 @@ __global__ __launch_bounds__(256) void k_force_gather_geom(int N, const int* __r
                                                            const float* __restrict__ drbf, int Rp,
                                                            const float* __restrict__ g_geo, int S,
                                                            float* __restrict__ f_out, const int* __restrict__ status,
-                                                           int epoch) {
+                                                           int epoch, EnergyFold ef) {
   const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), l = threadIdx.x & 63;
+  if (i < ef.B) {  // the per-fragment energy sums of the read-out (head.hip::hk_energy): wave i sums fragment i
+    float acc = 0.f;
+    for (int k = ef.fstart[i] + l; k < ef.fend[i]; k += 64) acc += ef.y[k];
+    acc = wave_sum(acc);
+    if (l == 0) ef.e_out[i] = (*status == epoch) ? __builtin_nanf("") : acc + ef.mean;
+  }
   if (i >= N) return;  // (wave-uniform)
   const int r0 = rowptr[i], din = rowptr[i + 1] - r0, c0 = colptr[i], tot = din + colptr[i + 1] - c0;
   float fx = 0.f, fy = 0.f, fz = 0.f;
@@ -474,13 +482,15 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
 }
 
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
-                    float* f_out, bool keep_g_ev) {
-  if (a.N <= 0) return 0;
+                    float* f_out, bool keep_g_ev, const EnergyFold& ef) {
+  if (a.N <= 0) return ef.B > 0 ? -22 : 0;
   if (a.N < 4096 && !keep_g_ev) {  // single-protein sizes: one launch, g_ev is not materialised
-    hipLaunchKernelGGL(k_force_gather_geom, dim3((a.N + 3) / 4), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm,
-                       a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S, f_out, a.status, a.epoch);
+    const int blocks = std::max((a.N + 3) / 4, (ef.B + 3) / 4);
+    hipLaunchKernelGGL(k_force_gather_geom, dim3(blocks), dim3(256), 0, st, a.N, a.rowptr, a.colptr, a.perm, a.geo,
+                       g_rbf, a.drbf, a.Rp, g_geo, a.S, f_out, a.status, a.epoch, ef);
     return 0;
   }
+  if (ef.B > 0) return -22;  // (the head only defers its energy sums when this launch takes the fused form)
   int blocks = (a.Emax + 255) / 256;
   if (blocks > 0)
     hipLaunchKernelGGL(k_bwd_geom, dim3(blocks), dim3(256), 0, st, a.ecount, a.geo, g_rbf, a.drbf, a.Rp, g_geo, a.S,

@@ -119,6 +119,10 @@ __global__ void hk_b_mul_dsilu(long long n, int act, const float* __restrict__ a
 #define VSN_HK(K) hipLaunchKernelGGL((D.act == VSN_ACT_SILU ? K<false> : K<true>)
 static inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
+bool head_defers_energy(const Dims& D, const HeadW& W) {
+  return W.defer_energy && W.fuse && D.N > 0 && D.N < 4096 && head_fused_supported(D);
+}
+
 int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, const float* vo,
                         const int* fstart, const int* fend, int B, float* e_out) {
   const int N = D.N, S = D.S, H = D.H, h2 = H / 2, ldp = H + h2;
@@ -132,8 +136,9 @@ int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const Hea
   if (W.fuse && head_fused_supported(D)) {
     // single-protein sizes: the node-local rest of the head, forward and reverse, is one launch
     rc |= launch_head_fused(st, D, W, Bf);
-    hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
-                                  W.status, W.epoch);
+    if (!head_defers_energy(D, W))
+      hipLaunchKernelGGL(hk_energy, dim3(nblk(B)), dim3(256), 0, st, B, fstart, fend, Bf.y, W.mean, e_out,
+                         W.status, W.epoch);
     return rc;
   }
   hipLaunchKernelGGL(hk_norm_s, dim3(nblk((long long)N * H)), dim3(256), 0, st, N, S, H, Bf.pv0, ldp, Bf.cat0,

@@ -119,9 +119,17 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n);
 bool gemm_group_ok(const GemmDesc* descs, int n);
 
 int launch_graph(hipStream_t st, const GraphArgs& a);
+// per-fragment energies e_out[b] = sum_{i in fragment b} y[i] + mean, folded into the force gather (B = 0: nothing)
+struct EnergyFold {
+  int B;
+  const int *fstart, *fend;
+  const float* y;
+  float mean;
+  float* e_out;
+};
 // keep_g_ev: the debug tap wants the per-edge adjoint in HBM; otherwise single-protein sizes fold it into the gather
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
-                    float* f_out, bool keep_g_ev);
+                    float* f_out, bool keep_g_ev, const EnergyFold& ef);
 
 // ---- forward ----
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
@@ -219,11 +227,15 @@ struct HeadW {
   const int* status;     // chunk status word and epoch (see GraphArgs): *status == epoch -> energies are NaN
   int epoch;
   int fuse;              // 1: single-protein sizes take the fused head kernel (head_fused.hip) when it fits in LDS
+  int defer_energy;      // 1 (fused head only): the per-fragment energy sums ride in the evaluation's LAST launch
+                         // (launch_bwd_geom's EnergyFold) instead of a launch of their own
 };
 struct HeadBuf {
   float *cat0, *pv0, *a0, *u0, *vec1o, *cat1, *p1, *a1b, *y;        // forward
   float *g_a1, *g_cat1, *g_p1, *g_vec1o, *g_u0, *g_h0, *g_cat0, *g_pv0;  // reverse
 };
+// true when launch_head_forward will leave the energy sums to launch_bwd_geom (both sides ask the same predicate)
+bool head_defers_energy(const Dims& D, const HeadW& W);
 // expects out_norm(x) already in Bf.cat0[:, :H] (row stride 2H)
 int launch_head_forward(hipStream_t st, const Dims& D, const HeadW& W, const HeadBuf& Bf, const float* vo,
                         const int* fstart, const int* fend, int B, float* e_out);
