@@ -135,6 +135,111 @@ __global__ __launch_bounds__(512) void k_big(const float* __restrict__ A, int ld
     }
 }
 
+// The library's own decomposition: 4 waves (one per SIMD), 128 x 128 per wave = 4 x 4 accumulators (256 registers).
+template <int EPI>
+__global__ __launch_bounds__(256) void k_big4(const float* __restrict__ A, int lda, const float* __restrict__ Bt, int ldb,
+                                              float* __restrict__ C, int ldc, const float* __restrict__ bias, int M, int Nc,
+                                              int K) {
+  extern __shared__ __attribute__((aligned(1024))) float smem[];  // 2 stages x 512 rows x 32 floats
+  constexpr int STAGE = 512 * 32;
+  const int tiles_n = Nc >> 8;
+  const int live = ((M + 255) >> 8) * tiles_n;
+  const int tile = xcd_block((int)blockIdx.x, live);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm << 8, col0 = tn << 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // LDS-DMA: waves 0-1 fill the A rows, waves 2-3 the B rows; 16 instructions each per stage
+  const float* gp[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int r = ((wave & 1) * 16 + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    if (wave < 2) {
+      int gr = row0 + r;
+      gr = gr < M ? gr : M - 1;
+      gp[q] = A + (size_t)gr * lda + c * 4;
+    } else {
+      gp[q] = Bt + (size_t)(col0 + r) * ldb + c * 4;
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned dma0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 16 * 1024);
+  auto dma = [&](int stage, int k0) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) glds16(gp[q] + k0, dma0 + (unsigned)stage * STAGE * 4 + q * 1024);
+  };
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int fa[4], fb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = (wm * 128 + i * 32 + l31) * 32;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = (256 + wn * 128 + j * 32 + l31) * 32;
+  int fo[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fo[kk] = ((kk * 2 + hi) ^ ((l31 >> 1) & 7)) << 2;
+  const int nkt = K >> 5;
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* st = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nkt) dma((kt + 1) & 1, (kt + 1) * 32);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + fa[i] + fo[kk]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + fb[j] + fo[kk]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = col0 + wn * 128 + j * 32 + l31;
+      const float bv = EPI == 1 ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 128 + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+        if (row < M) {
+          float* cp = C + (size_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (EPI == 2) v += *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
+template <int EPI>
+static void launch4(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias, int M, int Nc,
+                    int K) {
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)k_big4<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    set = true;
+  }
+  const int grid = ((M + 255) / 256) * (Nc / 256);
+  hipLaunchKernelGGL(k_big4<EPI>, dim3(grid), dim3(256), 128 * 1024, 0, A, lda, Bt, ldb, C, ldc, bias, M, Nc, K);
+}
+
 template <int EPI>
 static void launch(const float* A, int lda, const float* Bt, int ldb, float* C, int ldc, const float* bias, int M, int Nc,
                    int K) {
@@ -248,6 +353,10 @@ int main(int argc, char** argv) {
     report("256x256, 8 waves, LDS-DMA x2", [&] {
       if (s.acc) lab::launch<2>(A, s.K, B, s.K, C, s.Nc, nullptr, s.M, s.Nc, s.K);
       else lab::launch<1>(A, s.K, B, s.K, C, s.Nc, bias, s.M, s.Nc, s.K);
+    });
+    report("256x256, 4 waves (128x128 each)", [&] {
+      if (s.acc) lab::launch4<2>(A, s.K, B, s.K, C, s.Nc, nullptr, s.M, s.Nc, s.K);
+      else lab::launch4<1>(A, s.K, B, s.K, C, s.Nc, bias, s.M, s.Nc, s.K);
     });
     hipFree(A);
     hipFree(B);
