@@ -72,6 +72,31 @@ def test_fresh_seed_against_oracle_dipeptide_batch(lib_built):
     check(e, f, E64, F64)
 
 
+@pytest.mark.parametrize("sizes", [[0, 0, 1, 0, 0, 0, 0], [0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 2, 0]])
+def test_more_fragments_than_atoms(lib_built, sizes):
+    """Mostly empty fragments (B > N): the per-fragment energy sums ride in the force gather's launch, a wave per
+    fragment next to a wave per atom - every fragment gets its energy (empty ones the mean), whichever count is larger."""
+    hp = default_hparams(embedding_dimension=64, num_layers=2)
+    z, pos, start, end = random_fragments(5, sizes)
+    assert len(sizes) > len(z)
+    sd = make_state_dict(hp, seed=3)
+    E64, F64, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    from ai2bmd_amd.visnet_calculator import ViSNetModel
+
+    m = ViSNetModel(hp, sd, device="cuda:0")
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))  # (non-empty fragments only, like the reference)
+    check(e, f, E64, F64)
+    # the engine's own output has a slot per fragment: the empty ones hold the same value (the prior's mean)
+    e_all = torch.full((len(sizes),), float("nan"), device="cuda:0")
+    f_all = torch.empty(len(z), 3, device="cuda:0")
+    m.engine.forces_device(torch.as_tensor(z, dtype=torch.int64).cuda(), torch.as_tensor(pos, dtype=torch.float32).cuda(),
+                           start, end, e_all, f_all)
+    e_all = e_all.cpu().numpy()
+    empty = np.asarray(sizes) == 0
+    assert np.isfinite(e_all).all() and np.ptp(e_all[empty]) == 0.0
+    np.testing.assert_array_equal(e_all[~empty], e.ravel())
+
+
 def test_run_to_run_bit_reproducible(lib_built):
     g = load_golden("h64_l2")
     m = model_for(g["hparams"], g["weight_seed"])
