@@ -216,12 +216,7 @@ class LangevinHIP(_MDBase):
         self.x = torch.as_tensor(x0, device=device).contiguous()
         self.force_fn = force_fn
         self.inplace_forces = bool(inplace_forces)
-        ff = getattr(force_fn, "__self__", None)
-        tail = getattr(ff, "fused_tail", None)
-        fuse_tail = fuse_tail and os.environ.get("VSN_MD_FUSE", "1") != "0"  # A/B switch
-        self._ff = ff if (fuse_tail and inplace_forces and tail is not None and hasattr(ff, "exchange")
-                          and getattr(force_fn, "__name__", "") == "step" and tail[3].shape[0] == self.n
-                          and tail[3].device == torch.device(device)) else None
+        self._ff = self._fusable_evaluator(force_fn, device) if (fuse_tail and inplace_forces) else None
         self.tether_k = float(tether_k)
         self._x0 = x0.astype(np.float64)
         self.constraints = []
@@ -240,6 +235,21 @@ class LangevinHIP(_MDBase):
         self._init_observers(temperature_K)
         self._start_forces()
         self.steps = 0
+
+    def _fusable_evaluator(self, force_fn, device):
+        """the ShardedFragmentForces whose bound `step` is `force_fn`, if its HIP wiring (gather plan, combine plan,
+        buffers on this device, one row per atom of this system) allows the fused ends; else None"""
+        from .bonded import ShardedFragmentForces
+
+        if os.environ.get("VSN_MD_FUSE", "1") == "0":  # A/B switch
+            return None
+        ff = getattr(force_fn, "__self__", None)
+        if not isinstance(ff, ShardedFragmentForces) or getattr(force_fn, "__func__", None) is not ShardedFragmentForces.step:
+            return None
+        tail = ff.fused_tail
+        if tail is None or tail[3].shape[0] != self.n or tail[3].device != torch.device(device):
+            return None
+        return ff
 
     def _stream(self):
         return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
