@@ -1,0 +1,197 @@
+// Lab only (tools/lab/build_s3.py splices this into a COPY of csrc/gemm.hip; the product library never sees it): the
+// 64 x 64 tile of the grouped launch with both fp32 operands split into three bf16 terms and six
+// v_mfma_f32_32x32x16_bf16 products per 16-k block, fp32 accumulate (tools/lab/bf16x3_lab.hip has the stand-alone
+// measurement and the error analysis).  Same tile numbering, split-K slices, accumulate-from-C and epilogue as
+// gemm_body<64, 64, 2, 2, true>, so it drops into k_gemm_group behind a flag bit; the weights come as row-interleaved
+// planes [Nc][3][ldb] bf16 (made once per weight matrix by k_s3_split), the activations are split on their way into LDS.
+#pragma once
+// (spliced in INSIDE namespace vsn: <map> is included by the generated file in front of it)
+
+typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
+#define VSN_S3_FLAG (1 << 30)
+#ifndef S3_DB
+#define S3_DB 1  // 1: two LDS stages (48 KiB, 3 workgroups per CU), 0: one stage + two barriers per k-tile (24 KiB)
+#endif
+
+__device__ __forceinline__ void s3_split8(const f32x4 x0, const f32x4 x1, s3_bf16x8& hi, s3_bf16x8& mid, s3_bf16x8& lo) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float x = t < 4 ? x0[t] : x1[t - 4];
+    const __bf16 h = (__bf16)x;
+    const float r1 = x - (float)h;
+    const __bf16 m = (__bf16)r1;
+    hi[t] = h;
+    mid[t] = m;
+    lo[t] = (__bf16)(r1 - (float)m);
+  }
+}
+
+// byte offset of 16-byte chunk c (8 bf16 k-values) of row r in a 64-row x 64-byte plane
+__device__ __forceinline__ int s3_at(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
+
+__device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda, const unsigned short* __restrict__ B3,
+                                           int ldb, float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                           int M, const int* __restrict__ Mptr, int Nc, int K, int flags, int ksplit,
+                                           float* __restrict__ part, int block_id, float* __restrict__ smem_f) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  constexpr int PLANE = 64 * 64, STAGE = 6 * PLANE;  // bytes: A hi/mid/lo, B hi/mid/lo
+  unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_f);
+  int Meff = M;
+  if (Mptr) {
+    int md = *Mptr;
+    Meff = md < M ? md : M;
+  }
+  const int tiles_n = Nc / BN;
+  const int live = ((Meff + BM - 1) / BM) * tiles_n * ksplit;
+  if (block_id >= live) return;
+  const int bid = VSN_XCD_REMAP ? xcd_block(block_id, live) : block_id;
+  const int tile = bid / ksplit, ks = bid % ksplit;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nkt_all = K / BK;
+  const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
+  const int nkt = kt1 - kt0;
+
+  // staging role: tile row sr, 8-k chunk sj
+  const int sr = tid >> 2, sj = tid & 3;
+  const int ar = row0 + sr < Meff ? sr : Meff - 1 - row0;  // rows >= Meff are clamped: never stored
+  const float* __restrict__ ag = A + (size_t)(row0 + ar) * lda + (size_t)kt0 * BK + sj * 8;
+  const unsigned short* __restrict__ bg = B3 + (size_t)(col0 + sr) * 3 * ldb + (size_t)kt0 * BK + sj * 8;
+  const int soff = s3_at(sr, sj);
+  f32x4 ra0, ra1;
+  s3_bf16x8 rb[3];
+  auto gload = [&](int kt) {
+    ra0 = *reinterpret_cast<const f32x4*>(ag + kt * BK);
+    ra1 = *reinterpret_cast<const f32x4*>(ag + kt * BK + 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) rb[p] = *reinterpret_cast<const s3_bf16x8*>(bg + (size_t)p * ldb + kt * BK);
+  };
+  auto sstore = [&](int stage) {
+    unsigned char* base = smem + stage * STAGE + soff;
+    s3_bf16x8 h, m, l;
+    s3_split8(ra0, ra1, h, m, l);
+    *reinterpret_cast<s3_bf16x8*>(base) = h;
+    *reinterpret_cast<s3_bf16x8*>(base + PLANE) = m;
+    *reinterpret_cast<s3_bf16x8*>(base + 2 * PLANE) = l;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<s3_bf16x8*>(base + (3 + p) * PLANE) = rb[p];
+  };
+
+  const bool accum = (flags & 1) != 0;
+  const bool acc_out = accum && ksplit == 1;
+  const float bv = (bias && ksplit == 1) ? bias[col0 + wn * 32 + l31] : 0.f;
+  f32x16 acc;
+  if (acc_out) {  // accumulate mode: the accumulator starts from the old C values
+    const float* cp = C + (size_t)row0 * ldc + col0;
+    const int rlim = Meff - row0 - (wm * 32 + 4 * hi);
+    const unsigned off = (unsigned)(wm * 32 + 4 * hi) * (unsigned)ldc + (unsigned)(wn * 32 + l31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      acc[r] = dr < rlim ? cp[off + (unsigned)dr * (unsigned)ldc] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
+
+  const int fra = wm * 32 + l31, frb = wn * 32 + l31;
+  auto mfma6 = [&](const unsigned char* st, int kc) {
+    const int c = kc * 2 + hi;
+    s3_bf16x8 a[3], b[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      a[p] = *reinterpret_cast<const s3_bf16x8*>(st + p * PLANE + s3_at(fra, c));
+      b[p] = *reinterpret_cast<const s3_bf16x8*>(st + (3 + p) * PLANE + s3_at(frb, c));
+    }
+    // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+  };
+  gload(0);
+#if S3_DB
+  sstore(0);
+  if (1 < nkt) gload(1);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    mfma6(st, 0);
+    if (kt + 1 < nkt) {  // tile kt+1 (in registers) -> the other stage; the loads of tile kt+2 start
+      __builtin_amdgcn_sched_barrier(0);
+      sstore((kt & 1) ^ 1);
+      if (kt + 2 < nkt) gload(kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma6(st, 1);
+    __syncthreads();
+  }
+#else
+  for (int kt = 0; kt < nkt; ++kt) {
+    sstore(0);
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(smem, 0);
+    mfma6(smem, 1);
+    __syncthreads();
+  }
+#endif
+
+  float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
+  const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
+  const unsigned off = (unsigned)(wm * 32 + 4 * hi) * ldo + (unsigned)(wn * 32 + l31);
+  const int rlim = Meff - row0 - (wm * 32 + 4 * hi);
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r & 3) + 8 * (r >> 2) < rlim) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[r] + bv;
+}
+
+// W [Nc][ldb] fp32 -> planes [Nc][3][ldb] bf16 (hi, mid, lo)
+__global__ void k_s3_split(const float* __restrict__ W, size_t n, int ldb, unsigned short* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t r = i / ldb, k = i % ldb;
+  const float x = W[i];
+  const __bf16 h = (__bf16)x;
+  const float r1 = x - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  out[(r * 3 + 0) * ldb + k] = __builtin_bit_cast(unsigned short, h);
+  out[(r * 3 + 1) * ldb + k] = __builtin_bit_cast(unsigned short, m);
+  out[(r * 3 + 2) * ldb + k] = __builtin_bit_cast(unsigned short, l);
+}
+
+struct S3Entry {
+  unsigned short* planes;
+  size_t elems;
+};
+static int s3_mode() {
+  static const int m = [] {
+    const char* e = getenv("VSN_SPLIT3");
+    return e ? atoi(e) : 0;
+  }();
+  return m;
+}
+// swap a member's weight operand for its bf16 planes (made on first sight, on the launch stream) and mark it
+static void s3_patch(GemmDesc& d, hipStream_t st) {
+  static std::map<const float*, S3Entry> cache;
+  if (!s3_mode() || (d.flags & 2) || (d.ldb & 7) || (d.K & 31) || (d.Nc & 63)) return;
+  const size_t elems = (size_t)d.Nc * d.ldb;
+  auto it = cache.find(d.Bt);
+  if (it == cache.end() || it->second.elems < elems) {
+    unsigned short* p = nullptr;
+    if (hipMalloc((void**)&p, 3 * elems * sizeof(unsigned short)) != hipSuccess) return;
+    hipLaunchKernelGGL(k_s3_split, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, d.Bt, elems, d.ldb, p);
+    cache[d.Bt] = S3Entry{p, elems};  // (a replaced entry leaks: lab)
+    it = cache.find(d.Bt);
+  }
+  d.Bt = reinterpret_cast<const float*>(it->second.planes);
+  d.flags |= VSN_S3_FLAG;
+}
