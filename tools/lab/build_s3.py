@@ -2,7 +2,7 @@
 split products (tools/lab/gemm_s3_body.h) when VSN_SPLIT3=1 - NOT a product mode: the product sources are untouched, a
 patched COPY of csrc/gemm.hip is compiled into ai2bmd_amd/_ab/libvsn_s3.so (git-ignored) and selected with VSN_LIB.
 
-    python tools/lab/build_s3.py [--single-stage]     (-> libvsn_s3.so / libvsn_s3sb.so)
+    python tools/lab/build_s3.py [--single-stage | --b-in-registers]     (-> libvsn_s3.so / _s3sb.so / _s3br.so)
     VSN_LIB=ai2bmd_amd/_ab/libvsn_s3.so VSN_SPLIT3=1 python bench.py --no-secondary --no-cpu-baseline --steps 600
 """
 import os
@@ -46,11 +46,13 @@ def main():
     out = os.path.join(B.HERE, "_ab")
     os.makedirs(out, exist_ok=True)
     single = "--single-stage" in sys.argv
-    tag = "s3sb" if single else "s3"
+    breg = "--b-in-registers" in sys.argv  # weights packed in fragment order, straight from L2 (24 KiB of LDS: fits)
+    tag = "s3br" if breg else "s3sb" if single else "s3"
+    single = single or breg
     src = os.path.join(out, f"gemm_{tag}_gen.hip")
     open(src, "w").write(patched_source(single))
     obj = os.path.join(out, f"gemm_{tag}.o")
-    subprocess.run([B._hipcc(), *B.FLAGS, *(["-DS3_DB=0"] if single else []), "-I", B.CSRC, "-c", src, "-o", obj], check=True)
+    subprocess.run([B._hipcc(), *B.FLAGS, *(["-DS3_BREG=1"] if breg else ["-DS3_DB=0"] if single else []), "-I", B.CSRC, "-c", src, "-o", obj], check=True)
     objs = [obj if s_ == "gemm.hip" else os.path.join(B.OBJ, s_.replace(".hip", ".o")) for s_ in B.SOURCES]
     lib = os.path.join(out, f"libvsn_{tag}.so")
     subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)

@@ -9,6 +9,9 @@
 
 typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
 #define VSN_S3_FLAG (1 << 30)
+#ifndef S3_BREG
+#define S3_BREG 0  // 1: weight planes packed in MFMA-fragment order and streamed from L2 straight into registers (no LDS for B)
+#endif
 #ifndef S3_DB
 #define S3_DB 1  // 1: two LDS stages (48 KiB, 3 workgroups per CU), 0: one stage + two barriers per k-tile (24 KiB)
 #endif
@@ -153,6 +156,130 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     if ((r & 3) + 8 * (r >> 2) < rlim) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[r] + bv;
 }
 
+#if S3_BREG
+// packed weight planes: block (32 columns cb, 16 k kb, plane p) = 1 KiB = lane (n & 31) + 32 ((k & 15) >> 3), 8 bf16 each
+__host__ __device__ __forceinline__ size_t s3_pack(size_t n, size_t k, int p, size_t ldb) {
+  return ((((n >> 5) * (ldb >> 4) + (k >> 4)) * 3 + p) * 64 + (n & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7);
+}
+// the same tile with the B fragments straight from L2 (one coalesced KiB per wave, plane and 16-k block), prefetched a
+// k-tile ahead; LDS holds the three A planes only (two stages of 12 KiB, one barrier per k-tile)
+__device__ __forceinline__ void gemm_body3r(const float* __restrict__ A, int lda, const unsigned short* __restrict__ B3,
+                                            int ldb, float* __restrict__ C, int ldc, const float* __restrict__ bias,
+                                            int M, const int* __restrict__ Mptr, int Nc, int K, int flags, int ksplit,
+                                            float* __restrict__ part, int block_id, float* __restrict__ smem_f) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  constexpr int PLANE = 64 * 64, STAGE = 3 * PLANE;
+  unsigned char* const smem = reinterpret_cast<unsigned char*>(smem_f);
+  int Meff = M;
+  if (Mptr) {
+    int md = *Mptr;
+    Meff = md < M ? md : M;
+  }
+  const int tiles_n = Nc / BN;
+  const int live = ((Meff + BM - 1) / BM) * tiles_n * ksplit;
+  if (block_id >= live) return;
+  const int bid = VSN_XCD_REMAP ? xcd_block(block_id, live) : block_id;
+  const int tile = bid / ksplit, ks = bid % ksplit;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int row0 = tm * BM, col0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nkt_all = K / BK;
+  const int kt0 = (int)((long long)nkt_all * ks / ksplit), kt1 = (int)((long long)nkt_all * (ks + 1) / ksplit);
+  const int nkt = kt1 - kt0;
+  const int sr = tid >> 2, sj = tid & 3;
+  const int ar = row0 + sr < Meff ? sr : Meff - 1 - row0;
+  const float* __restrict__ ag = A + (size_t)(row0 + ar) * lda + (size_t)kt0 * BK + sj * 8;
+  const int soff = s3_at(sr, sj);
+  // this wave's 32-column block, its first 16-k block: fragments follow at 3 KiB per 16-k block
+  const unsigned short* __restrict__ bw =
+      B3 + ((((size_t)((col0 >> 5) + wn) * (size_t)(ldb >> 4) + (size_t)kt0 * 2) * 3) * 64 + lane) * 8;
+  f32x4 ra0, ra1;
+  auto gloadA = [&](int kt) {
+    ra0 = *reinterpret_cast<const f32x4*>(ag + kt * BK);
+    ra1 = *reinterpret_cast<const f32x4*>(ag + kt * BK + 4);
+  };
+  auto sstoreA = [&](int stage) {
+    unsigned char* base = smem + stage * STAGE + soff;
+    s3_bf16x8 h, m, l;
+    s3_split8(ra0, ra1, h, m, l);
+    *reinterpret_cast<s3_bf16x8*>(base) = h;
+    *reinterpret_cast<s3_bf16x8*>(base + PLANE) = m;
+    *reinterpret_cast<s3_bf16x8*>(base + 2 * PLANE) = l;
+  };
+  s3_bf16x8 bn[2][3], bc[2][3];
+  auto gloadB = [&](int kt) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        bn[kc][p] = *reinterpret_cast<const s3_bf16x8*>(bw + ((size_t)(kt * 2 + kc) * 3 + p) * 512);
+  };
+  const bool accum = (flags & 1) != 0;
+  const bool acc_out = accum && ksplit == 1;
+  const float bv = (bias && ksplit == 1) ? bias[col0 + wn * 32 + l31] : 0.f;
+  f32x16 acc;
+  if (acc_out) {
+    const float* cp = C + (size_t)row0 * ldc + col0;
+    const int rlim = Meff - row0 - (wm * 32 + 4 * hi);
+    const unsigned off = (unsigned)(wm * 32 + 4 * hi) * (unsigned)ldc + (unsigned)(wn * 32 + l31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int dr = (r & 3) + 8 * (r >> 2);
+      acc[r] = dr < rlim ? cp[off + (unsigned)dr * (unsigned)ldc] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  }
+  const int fra = wm * 32 + l31;
+  auto mfma6 = [&](const unsigned char* st, int kc) {
+    const int c = kc * 2 + hi;
+    s3_bf16x8 a[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const s3_bf16x8*>(st + p * PLANE + s3_at(fra, c));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bc[kc][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], bc[kc][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bc[kc][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bc[kc][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bc[kc][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bc[kc][0], acc, 0, 0, 0);
+  };
+  gloadA(0);
+  gloadB(0);
+  sstoreA(0);
+  if (1 < nkt) gloadA(1);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bc[kc][p] = bn[kc][p];
+    if (kt + 1 < nkt) gloadB(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma6(st, 0);
+    if (kt + 1 < nkt) {
+      __builtin_amdgcn_sched_barrier(0);
+      sstoreA((kt & 1) ^ 1);
+      if (kt + 2 < nkt) gloadA(kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma6(st, 1);
+    __syncthreads();
+  }
+  float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
+  const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
+  const unsigned off = (unsigned)(wm * 32 + 4 * hi) * ldo + (unsigned)(wn * 32 + l31);
+  const int rlim = Meff - row0 - (wm * 32 + 4 * hi);
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    if ((r & 3) + 8 * (r >> 2) < rlim) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[r] + bv;
+}
+#define gemm_body3 gemm_body3r
+#endif
+
 // W [Nc][ldb] fp32 -> planes [Nc][3][ldb] bf16 (hi, mid, lo)
 __global__ void k_s3_split(const float* __restrict__ W, size_t n, int ldb, unsigned short* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,9 +290,15 @@ __global__ void k_s3_split(const float* __restrict__ W, size_t n, int ldb, unsig
   const float r1 = x - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
+#if S3_BREG
+  out[s3_pack(r, k, 0, (size_t)ldb)] = __builtin_bit_cast(unsigned short, h);
+  out[s3_pack(r, k, 1, (size_t)ldb)] = __builtin_bit_cast(unsigned short, m);
+  out[s3_pack(r, k, 2, (size_t)ldb)] = __builtin_bit_cast(unsigned short, l);
+#else
   out[(r * 3 + 0) * ldb + k] = __builtin_bit_cast(unsigned short, h);
   out[(r * 3 + 1) * ldb + k] = __builtin_bit_cast(unsigned short, m);
   out[(r * 3 + 2) * ldb + k] = __builtin_bit_cast(unsigned short, l);
+#endif
 }
 
 struct S3Entry {
@@ -182,7 +315,7 @@ static int s3_mode() {
 // swap a member's weight operand for its bf16 planes (made on first sight, on the launch stream) and mark it
 static void s3_patch(GemmDesc& d, hipStream_t st) {
   static std::map<const float*, S3Entry> cache;
-  if (!s3_mode() || (d.flags & 2) || (d.ldb & 7) || (d.K & 31) || (d.Nc & 63)) return;
+  if (!s3_mode() || (d.flags & 2) || (d.ldb & 15) || (d.K & 31) || (d.Nc & 63)) return;
   const size_t elems = (size_t)d.Nc * d.ldb;
   auto it = cache.find(d.Bt);
   if (it == cache.end() || it->second.elems < elems) {
