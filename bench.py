@@ -243,8 +243,11 @@ def traffic_from_profile(workload, kernel):
         return None, (f"{TRAFFIC_PROFILE} was measured on another build of csrc/ (digest "
                       f"{str(d.get('build_digest'))[:12]} != {str(dig)[:12]}): stale, not reported - re-run "
                       "tools/profile_round.sh")
-    return d.get(workload, {}).get(kernel), (f"{TRAFFIC_PROFILE} (rocprofv3 PMC passes of this command on this "
-                                             "build, per launch; not re-measured in this run)")
+    val = d.get(workload, {}).get(kernel)
+    if val is None:
+        return None, f"{TRAFFIC_PROFILE} holds no PMC passes of this workload / kernel ({workload}, {kernel})"
+    return val, (f"{TRAFFIC_PROFILE} (rocprofv3 PMC passes of this command on this build, per launch; not "
+                 "re-measured in this run)")
 
 
 def roofline_block(eng, nprof, workload, flops_step, ms_per_step):
@@ -390,8 +393,10 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
         md.step()
     torch.cuda.synchronize()
     flops_step = 2.0 * fwd_flops(n_loc, edges_after, H, L, S, R)
-    roof = roofline_block(eng, nprof, f"{pname}_md", flops_step, ms)
-    roof_hbm = roofline_hbm_block(eng, nprof, f"{pname}_md")
+    # (the PMC passes under profiles/ are of the H=256 / L=9 network: another network has no counter figure)
+    wkey = f"{pname}_md" if (H, L) == (256, 9) else f"{pname}_md_h{H}l{L}"
+    roof = roofline_block(eng, nprof, wkey, flops_step, ms)
+    roof_hbm = roofline_hbm_block(eng, nprof, wkey)
     eng.set_option("profile", 0)
     workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
                 f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
