@@ -124,6 +124,59 @@ def combine_numpy(n_prot, e_dip, f_dip, e_ace, f_ace, select_index, origin_index
 
 
 # ------------------------------------------------------------------------------------
+class _HipTail:
+    """The two ends of a sharded step on the device, through the C ABI: fragment gather + cap-hydrogen placement
+    (`vsn_build_fragments`) and the deterministic combine (`vsn_combine[_with_energy]`).  `for_engine` talks to the
+    device only through this object and the engine, so the CPU tests can run the SAME wiring (exchange-buffer views,
+    slot layout, remapped combine plan) over gloo with stand-ins for both (tests/test_fragmentation_and_sharding.py)."""
+
+    def __init__(self, device, index):
+        self.device, self.index, self.L = device, index, capi.lib()
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device)
+
+    def _sp(self, st):
+        return C.c_void_p(st.cuda_stream)
+
+    def fragplan(self, src, acc, tow, ln):
+        fp = C.c_void_p()
+        rc = self.L.vsn_fragplan_create(C.byref(fp), self.index, len(src), capi.i64_ptr(src), capi.i64_ptr(acc),
+                                        capi.i64_ptr(tow), ln.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc:
+            raise RuntimeError(f"vsn_fragplan_create failed ({rc})")
+        return fp
+
+    def build(self, fp, prot_pos, pos_geo, st):
+        rc = self.L.vsn_build_fragments(fp, C.c_void_p(prot_pos.data_ptr()), C.c_void_p(pos_geo.data_ptr()), self._sp(st))
+        if rc:
+            raise RuntimeError(f"vsn_build_fragments failed ({rc})")
+
+    def combine_plan(self, n_prot, row_of_cat, n_dip_rows, select_index, origin_index, e_idx, e_sgn):
+        cp = C.c_void_p()
+        rc = self.L.vsn_combine_plan_create(C.byref(cp), self.index, n_prot, len(row_of_cat), n_dip_rows,
+                                            capi.i64_ptr(row_of_cat), capi.i64_ptr(select_index),
+                                            capi.i64_ptr(origin_index), len(select_index))
+        if rc:
+            raise RuntimeError(f"vsn_combine_plan_create failed ({rc})")
+        rc = self.L.vsn_combine_plan_set_energy(cp, len(e_idx), capi.i64_ptr(e_idx),
+                                                e_sgn.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc:
+            raise RuntimeError(f"vsn_combine_plan_set_energy failed ({rc})")
+        return cp
+
+    def combine(self, cp, buf, F_prot, st):
+        rc = self.L.vsn_combine(cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()), self._sp(st))
+        if rc:
+            raise RuntimeError(f"vsn_combine failed ({rc})")
+
+    def combine_with_energy(self, cp, buf, F_prot, E_tot, st):
+        rc = self.L.vsn_combine_with_energy(cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
+                                            C.c_void_p(E_tot.data_ptr()), self._sp(st))
+        if rc:
+            raise RuntimeError(f"vsn_combine_with_energy failed ({rc})")
+
+
 class ShardedFragmentForces:
     """Device-resident protein -> (E, F[n_prot,3]) evaluator, one instance per rank.
 
@@ -211,14 +264,16 @@ class ShardedFragmentForces:
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
     def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None,
-                   force_collective=False, balance: str = "atoms"):
+                   force_collective=False, balance: str = "atoms", tail=None):
         """hydrogen: optional ai2bmd_amd.hydrogen.HydrogenPlan - relax the cap hydrogens every call like
         DistanceFragment.get_fragments (distancefrag.py:76-82).  The relaxation couples all dipeptides, so with
-        it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard."""
+        it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard.
+        tail: the device ends (default: the HIP kernels through the C ABI, `_HipTail`); the CPU tests pass a torch
+        stand-in together with a stand-in engine to run this very wiring over gloo."""
         dev = engine.device
         self = cls(plan, rank, world, dev, group, balance=balance)
         self.force_collective = bool(force_collective)
-        L = capi.lib()
+        tail = tail or _HipTail(dev, engine.index)
         lo, hi = self.atom_lo[rank], self.atom_hi[rank]
         # fragment geometry plan restricted to this rank's rows (all rows when the caps are relaxed)
         g_lo, g_hi = (0, len(plan.z)) if hydrogen is not None else (lo, hi)
@@ -226,22 +281,14 @@ class ShardedFragmentForces:
         acc = np.ascontiguousarray(plan.acceptor[g_lo:g_hi])
         tow = np.ascontiguousarray(plan.toward[g_lo:g_hi])
         ln = np.ascontiguousarray(plan.length[g_lo:g_hi], dtype=np.float32)
-        self._fp = C.c_void_p()
-        rc = L.vsn_fragplan_create(C.byref(self._fp), engine.index, g_hi - g_lo, capi.i64_ptr(src),
-                                   capi.i64_ptr(acc), capi.i64_ptr(tow), ln.ctypes.data_as(C.POINTER(C.c_float)))
-        if rc:
-            raise RuntimeError(f"vsn_fragplan_create failed ({rc})")
+        self._fp = tail.fragplan(src, acc, tow, ln)
         # the combine plan reads straight from the padded all-gather buffer (rows of 3 floats)
         rows = self.gathered_force_rows() // 3
         row_of_cat = np.ascontiguousarray(rows[plan.row_of_cat])
-        self._cp = C.c_void_p()
-        rc = L.vsn_combine_plan_create(C.byref(self._cp), engine.index, plan.n_prot, len(row_of_cat),
-                                       plan.n_dip_rows, capi.i64_ptr(row_of_cat),
-                                       capi.i64_ptr(np.ascontiguousarray(plan.select_index)),
-                                       capi.i64_ptr(np.ascontiguousarray(plan.origin_index)),
-                                       len(plan.select_index))
-        if rc:
-            raise RuntimeError(f"vsn_combine_plan_create failed ({rc})")
+        e_idx = np.ascontiguousarray(self._e_index.cpu().numpy(), dtype=np.int64)
+        e_sgn = np.ascontiguousarray(self._e_sign.cpu().numpy(), dtype=np.float32)
+        self._cp = tail.combine_plan(plan.n_prot, row_of_cat, plan.n_dip_rows, np.ascontiguousarray(plan.select_index),
+                                     np.ascontiguousarray(plan.origin_index), e_idx, e_sgn)
         z_loc = torch.as_tensor(plan.z[lo:hi], dtype=torch.int64).to(dev)
         pos_geo = torch.empty(max(g_hi - g_lo, 1), 3, dtype=torch.float32, device=dev)
         pos_loc = pos_geo[lo - g_lo: max(hi - g_lo, lo - g_lo + 1)]
@@ -260,13 +307,10 @@ class ShardedFragmentForces:
         F_prot = torch.empty(plan.n_prot, 3, dtype=torch.float32, device=dev)
 
         def local_fn(prot_pos, prebuilt=False):
-            st = torch.cuda.current_stream(dev)
+            st = tail.stream()
             if nloc:
                 if not prebuilt:
-                    rc_ = L.vsn_build_fragments(self._fp, C.c_void_p(prot_pos.data_ptr()),
-                                                C.c_void_p(pos_geo.data_ptr()), C.c_void_p(st.cuda_stream))
-                    if rc_:
-                        raise RuntimeError(f"vsn_build_fragments failed ({rc_})")
+                    tail.build(self._fp, prot_pos, pos_geo, st)
                 if self.relaxer is not None:
                     self.relaxer.run(pos_geo, st)
                 engine.forces_device(z_loc[:nloc], pos_loc[:nloc], self.local_start, self.local_end, e_loc[:bloc],
@@ -274,31 +318,17 @@ class ShardedFragmentForces:
             return e_loc[:bloc], f_loc[:nloc]
 
         def combine_fn(buf):
-            st = torch.cuda.current_stream(dev)
-            rc_ = L.vsn_combine(self._cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
-                                C.c_void_p(st.cuda_stream))
-            if rc_:
-                raise RuntimeError(f"vsn_combine failed ({rc_})")
+            tail.combine(self._cp, buf, F_prot, tail.stream())
             return F_prot
 
-        e_idx = np.ascontiguousarray(self._e_index.cpu().numpy(), dtype=np.int64)
-        e_sgn = np.ascontiguousarray(self._e_sign.cpu().numpy(), dtype=np.float32)
-        rc = L.vsn_combine_plan_set_energy(self._cp, len(e_idx), capi.i64_ptr(e_idx),
-                                           e_sgn.ctypes.data_as(C.POINTER(C.c_float)))
-        if rc:
-            raise RuntimeError(f"vsn_combine_plan_set_energy failed ({rc})")
         E_tot = torch.zeros(1, dtype=torch.float32, device=dev)
 
         def combine_energy_fn(buf):
-            st = torch.cuda.current_stream(dev)
-            rc_ = L.vsn_combine_with_energy(self._cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
-                                            C.c_void_p(E_tot.data_ptr()), C.c_void_p(st.cuda_stream))
-            if rc_:
-                raise RuntimeError(f"vsn_combine_with_energy failed ({rc_})")
+            tail.combine_with_energy(self._cp, buf, F_prot, E_tot, tail.stream())
             return E_tot[0], F_prot
 
         self.local_fn, self.combine_fn, self.combine_energy_fn = local_fn, combine_fn, combine_energy_fn
         # what the integrator's fused halves need (LangevinHIP: vsn_md_half1_build / vsn_md_combine_half2)
-        self.fused_tail = (self._fp, self._cp, pos_geo, F_prot, E_tot) if nloc else None
-        self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot, E_tot)
+        self.fused_tail = (self._fp, self._cp, pos_geo, F_prot, E_tot) if (nloc and isinstance(tail, _HipTail)) else None
+        self._keep = (z_loc, pos_geo, pos_loc, e_loc, f_loc, F_prot, E_tot, tail)
         return self

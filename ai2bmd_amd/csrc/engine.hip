@@ -719,13 +719,14 @@ static void snapshot(vsn_ctx* c, hipStream_t st, const char* name, int layer, co
   hipMemcpyAsync(v[layer], p, elems * sizeof(float), hipMemcpyDeviceToDevice, st);
 }
 
-// profile mode: HIP events around one scatter-path launch (same stream), resolved after the chunk
+// profile mode: the scatter-path launch made inside this scope carries two events on its dispatch packet
+// (layer_fwd.hip, launch_maybe_timed): their elapsed time is the kernel's own begin..end, resolved after the chunk
 struct ScatterBracket {
   vsn_ctx* c;
-  hipStream_t st;
   bool on;
-  ScatterBracket(vsn_ctx* c_, hipStream_t st_, int kind, int N, bool with_update, bool fused_norm)
-      : c(c_), st(st_), on(c_->profile) {
+  LaunchEvents ev{};
+  ScatterBracket(vsn_ctx* c_, hipStream_t, int kind, int N, bool with_update, bool fused_norm)
+      : c(c_), on(c_->profile) {
     if (!on) return;
     vsn_ctx::SRec r;
     r.kind = kind;
@@ -734,13 +735,23 @@ struct ScatterBracket {
     r.fused_norm = fused_norm;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
-    hipEventRecord(r.a, st);
+    ev.a = r.a;
+    ev.b = r.b;
     c->srecs.push_back(r);
+    set_launch_events(&ev);
   }
   ~ScatterBracket() {
-    if (on) hipEventRecord(c->srecs.back().b, st);
+    if (on) set_launch_events(nullptr);  // (the launch consumed it; a launch that was skipped must not leak it on)
   }
 };
+
+static void drop_scatter_records(vsn_ctx* c) {
+  for (auto& r : c->srecs) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  c->srecs.clear();
+}
 
 // ---------------------------------------------------------------------------------
 // one chunk: forward + reverse
@@ -1145,6 +1156,7 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
     }
     GemmProfiler gp;
     hipEvent_t empty[16];
+    drop_scatter_records(c);  // (records of a call that failed half-way never reach the sums)
     if (c->profile) {
       set_gemm_profiler(&gp);
       // what an event bracket itself costs on this stream: 8 brackets around nothing, mid-stream (the device is
@@ -1155,7 +1167,18 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       }
     }
     int rc0 = ensure_ws(c, (int)(a1 - a0), (int)eb, (int)(b1 - b0));
-    if (rc0) return rc0;
+    if (rc0) {
+      set_gemm_profiler(nullptr);
+      if (c->profile) {
+        hipStreamSynchronize(st);
+        for (int k = 0; k < 16; ++k) hipEventDestroy(empty[k]);
+        for (auto& r : gp.recs) {
+          hipEventDestroy(r.a);
+          hipEventDestroy(r.b);
+        }
+      }
+      return rc0;
+    }
     set_gemm_splitk_workspace(c->splitk, c->splitk_elems);
     int rc = run_chunk(c, st, dev_z + a0, dev_pos + 3 * a0, fs, fe, (int)(a1 - a0), (int)(b1 - b0), (int)eb,
                        (int)maxfrag, dev_e_out + b0, dev_f_out + 3 * a0);
@@ -1176,9 +1199,10 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       for (auto& r : c->srecs) {
         // algorithmic (compulsory) HBM bytes of the launch: every array it touches once
         float ms = 0.f;
-        hipEventElapsedTime(&ms, r.a, r.b);
+        const bool timed = hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess;
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
+        if (!timed) continue;
         const double H = c->H, S = c->S, n = r.N, e = E;
         double fl;
         if (r.kind == 0)  // edge attention (+ edge update): pe[dk|dv], C, src | qkv | m, A  (+ pe[f], f r/w, d, vp[wt|ws])
@@ -1193,9 +1217,10 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       c->srecs.clear();
       for (auto& r : gp.recs) {
         float ms = 0.f;
-        hipEventElapsedTime(&ms, r.a, r.b);
+        const bool timed = hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess;
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
+        if (!timed) continue;
         c->prof[r.variant][0] += 1;
         c->prof[r.variant][1] += ms;
         if (r.group_n > 0) {

@@ -109,6 +109,12 @@ struct GemmProfiler {
   std::vector<Rec> recs;
 };
 void set_gemm_profiler(GemmProfiler* p);  // thread-local; nullptr disables
+// profile mode, scatter path: the NEXT launch of k_edge_attn / k_edge_attn_update / k_node_update on this thread
+// carries these two events on its dispatch packet (their elapsed time = the kernel's begin..end timestamps)
+struct LaunchEvents {
+  hipEvent_t a, b;
+};
+void set_launch_events(const LaunchEvents* ev);  // thread-local; consumed by that launch
 void set_gemm_splitk_workspace(float* p, size_t elems);  // thread-local scratch for split-K partials
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,

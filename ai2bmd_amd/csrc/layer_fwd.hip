@@ -14,6 +14,8 @@
 // edge_update), :206-209 (vector_rejection); utils.py:165-249 (VecLayerNorm).
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -524,6 +526,40 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(
 }
 
 // ---- launchers -------------------------------------------------------------------
+// Profile mode (engine.hip, ScatterBracket): the scatter-path launches carry a pair of events ON THEIR DISPATCH
+// PACKET (hipExtLaunchKernelGGL).  The elapsed time between the two is the kernel's own begin / end timestamp - the
+// pair rocprofv3's kernel trace records - not a stream bracket whose marker packets add a size-dependent gap.
+static thread_local const LaunchEvents* tl_launch_ev = nullptr;
+void set_launch_events(const LaunchEvents* ev) { tl_launch_ev = ev; }
+template <typename... KA, typename... A>
+static inline void launch_maybe_timed(void (*kern)(KA...), dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
+  if (tl_launch_ev) {
+    const LaunchEvents ev = *tl_launch_ev;
+    tl_launch_ev = nullptr;
+    hipExtLaunchKernelGGL<KA...>(kern, g, b, lds, st, ev.a, ev.b, 0, static_cast<KA>(a)...);
+  } else {
+    hipLaunchKernelGGL(kern, g, b, lds, st, static_cast<KA>(a)...);
+  }
+}
+#define VSN_KL(NAME)                                                                       \
+  template <int V, int S, int W, bool G>                                                   \
+  struct KL_##NAME {                                                                       \
+    template <typename... A>                                                               \
+    static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {                 \
+      launch_maybe_timed(NAME<V, S, W, G>, g, b, lds, st, a...);                           \
+    }                                                                                      \
+  }
+VSN_KL(k_edge_attn);
+VSN_KL(k_edge_attn_update);
+VSN_KL(k_node_update);
+#undef VSN_KL
+#define VSN_LAUNCH_ACT_TIMED(KN, RK, ...)                                                               \
+  do {                                                                                                  \
+    const int w__ = pick_wpn(D.N);                                                                      \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KL_##KN,                                                       \
+                     ::go(node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st, __VA_ARGS__)); \
+  } while (0)
 #define VSN_LAUNCH_ACT(KN, RK, ...)                                                                     \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
@@ -561,7 +597,7 @@ int launch_node_norm(hipStream_t st, const Dims& D, const float* x, const float*
 }
 int launch_edge_attn(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH_ACT(k_edge_attn, 1, D, qkv, pe, m, A);
+  VSN_LAUNCH_ACT_TIMED(k_edge_attn, 1, D, qkv, pe, m, A);
   return 0;
 }
 int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, const float* pe, float* m, float* A,
@@ -569,15 +605,15 @@ int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, con
   if (D.N <= 0) return 0;
   const int w__ = pick_wpn(D.N);
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
-  VSN_DISPATCH_VSA(D.H, D.S, w__, g__, k_edge_attn_update,
-                   <<<2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st>>>(D, qkv, pe, m, A,
-                                                                                                    vp, f));
+  VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KL_k_edge_attn_update,
+                   ::go(2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st, D, qkv, pe, m, A,
+                        vp, f));
   return 0;
 }
 int launch_node_update(hipStream_t st, const Dims& D, const float* tpre, const float* vh, const float* vp,
                        const float* o, float* x, float* vec, const NextNorm& nn) {
   if (D.N <= 0) return 0;
-  VSN_LAUNCH_ACT(k_node_update, D.S, D, tpre, vh, vp, o, x, vec, nn);
+  VSN_LAUNCH_ACT_TIMED(k_node_update, D.S, D, tpre, vh, vp, o, x, vec, nn);
   return 0;
 }
 int launch_edge_update(hipStream_t st, const Dims& D, const float* vp, const float* pe, float* f) {

@@ -257,6 +257,8 @@ class LangevinHIP(_MDBase):
     def _start_forces(self):
         C = self._C
         self.E_model, F = self.force_fn(self.x)
+        if not self.inplace_forces:
+            F = F.clone()  # the restraint kernel adds into F: never into a tensor the caller may own / cache
         self.F = F if F.is_contiguous() else F.contiguous()
         rc = self._L.vsn_md_restrain(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.F.data_ptr()), self._stream())
         if rc:

@@ -101,6 +101,101 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_FOR_ENGINE = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from ai2bmd_amd.bonded import ShardedFragmentForces
+from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, fragment_positions, combine_host
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_ww.npz"))
+prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+plan = build_plan(prot)
+
+def stub_force(pos):  # deterministic per-row function standing in for the network
+    return torch.stack([torch.sin(pos[:, 0]) + pos[:, 1], pos[:, 2] ** 2, pos[:, 0] * pos[:, 1]], 1)
+
+class FakeEngine:
+    """stands in for ViSNetEngine: same call, writes INTO the views it is handed (that aliasing is the test)"""
+    device, index = "cpu", 0
+    calls = 0
+    def forces_device(self, z, pos, start, end, e_out, f_out, stream=None):
+        assert len(z) == len(pos) == len(f_out) and len(start) == len(end) == len(e_out)
+        assert int(start[0]) == 0 and int(end[-1]) == len(z)          # rebased to the shard
+        f_out.copy_(stub_force(pos))
+        for b, (s, e_) in enumerate(zip(start, end)):
+            e_out[b] = pos[int(s):int(e_)].sum()
+        self.calls += 1
+
+class TorchTail:
+    """stands in for _HipTail (vsn_build_fragments / vsn_combine_with_energy) with the same plan arguments"""
+    def stream(self):
+        return None
+    def fragplan(self, src, acc, tow, ln):
+        return tuple(torch.as_tensor(np.asarray(a)) for a in (src, acc, tow, ln))
+    def build(self, fp, prot_pos, pos_geo, st):
+        src, acc, tow, ln = fp
+        m = src >= 0
+        out = torch.zeros(len(src), 3)
+        out[m] = prot_pos[src[m]]
+        a = prot_pos[acc[~m]]
+        v = prot_pos[tow[~m]] - a
+        out[~m] = a + v / v.norm(dim=1, keepdim=True) * ln[~m][:, None]
+        pos_geo[: len(src)] = out
+    def combine_plan(self, n_prot, row_of_cat, n_dip_rows, select, origin, e_idx, e_sgn):
+        sel = np.asarray(select)
+        return dict(rows=torch.as_tensor(np.asarray(row_of_cat)[sel]), origin=torch.as_tensor(np.asarray(origin)),
+                    sign=torch.as_tensor(np.where(sel < n_dip_rows, 1.0, -1.0).astype(np.float32)),
+                    e_idx=torch.as_tensor(e_idx), e_sgn=torch.as_tensor(e_sgn))
+    def combine(self, cp, buf, F_prot, st):
+        F_prot.zero_()
+        F_prot.index_add_(0, cp["origin"], buf.view(-1, 3)[cp["rows"]] * cp["sign"][:, None])
+    def combine_with_energy(self, cp, buf, F_prot, E_tot, st):
+        self.combine(cp, buf, F_prot, st)
+        E_tot[0] = (buf[cp["e_idx"]] * cp["e_sgn"]).sum()
+
+eng = FakeEngine()
+ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, tail=TorchTail())
+assert ff.direct and ff.fused_tail is None
+x = torch.as_tensor(prot.positions, dtype=torch.float32)
+for it in range(2):  # second call: the exchange buffers are reused
+    xs = x + 0.01 * it
+    E, F = ff.step(xs)
+    full = fragment_positions(plan, xs.numpy().astype(np.float64))
+    e_ref = np.array([full[s:e_].sum() for s, e_ in zip(plan.start, plan.end)])
+    E_ref, F_ref = combine_host(plan, e_ref[(plan.end - plan.start) > 0], stub_force(torch.as_tensor(full)).numpy())
+    assert abs(float(E) - E_ref) < 1e-2 * max(1, abs(E_ref)), (float(E), E_ref)
+    assert np.abs(F.numpy() - F_ref).max() < 1e-3, np.abs(F.numpy() - F_ref).max()
+assert eng.calls == 2
+# this rank's slot of the gathered buffer IS what the engine wrote through the views; the other rank's slot arrived
+lo, hi = ff.atom_lo[rank], ff.atom_hi[rank]
+mine = ff.recv[rank * ff.slot: rank * ff.slot + (hi - lo) * 3].view(-1, 3)
+assert torch.equal(mine, stub_force(ff.frag_pos[: hi - lo]))
+other = 1 - rank
+assert ff.recv[other * ff.slot: other * ff.slot + ff.rows[other] * 3].abs().sum() > 0
+# without the relaxation a rank gathers only ITS rows of the fragment geometry
+assert ff.frag_pos.shape[0] == hi - lo
+print(f"rank {rank} for_engine ok rows={ff.local_rows} frags={ff.f1 - ff.f0} slot={ff.slot}")
+dist.destroy_process_group()
+'''
+
+
+def test_for_engine_wiring_world2_gloo(tmp_path):
+    """The PRODUCT wiring of the N > 1 path - `ShardedFragmentForces.for_engine`: shard-rebased fragment offsets, the
+    engine writing through views into the exchange buffer, one all-gather, the combine plan remapped onto the padded
+    gathered buffer - run by two gloo ranks with stand-ins for the engine and the two HIP ends (same arguments, torch
+    arithmetic).  RCCL differs from this only in the backend string."""
+    script = tmp_path / "worker_fe.py"
+    script.write_text(WORKER_FOR_ENGINE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", str(script), ROOT]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 for_engine ok" in r.stdout and "rank 1 for_engine ok" in r.stdout
+
+
 def test_sharded_path_world2_gloo(tmp_path, lib_built):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)

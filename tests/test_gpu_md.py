@@ -163,3 +163,35 @@ def test_observers_preequilibration_and_runaway_guard(lib_built):
     hot.v = hot.v * 3.0                                               # 9x the kinetic energy
     with pytest.raises(TemperatureRunawayError):
         hot.printenergy(quiet=True)
+
+
+def test_constant_force_tensor_is_never_written_with_inplace_forces_off(lib_built):
+    """`inplace_forces=False` (md.py): a force_fn that hands back a CACHED tensor keeps it untouched - at
+    construction, through repeated set_constraints (each re-evaluates the start forces and adds the restraint
+    forces) and through steps - and the integrator's own forces are cache + restraints, not an accumulation."""
+    from ai2bmd_amd.md import Hookean, LangevinHIP, hookean_forces
+
+    rng = np.random.default_rng(11)
+    n = 64
+    numbers = rng.choice([1, 6, 7, 8], size=n)
+    pos = (rng.standard_normal((n, 3)) * 2).astype(np.float32)
+    cached = torch.as_tensor(rng.standard_normal((n, 3)).astype(np.float32), device="cuda:0")
+    keep = cached.clone()
+
+    def fn(x):
+        return torch.zeros((), device=x.device), cached
+
+    md = LangevinHIP(numbers, pos, fn, "cuda:0", temperature_K=0.0, seed=1, tether_k=0.8, inplace_forces=False)
+    assert torch.equal(cached, keep)
+    cons = [Hookean(a1=int(i), a2=np.asarray(pos[i] + 0.3, dtype=np.float64), k=2.0, rt=0.0) for i in range(0, n, 4)]
+    for _ in range(3):
+        md.set_constraints(cons)
+        torch.cuda.synchronize()
+        assert torch.equal(cached, keep)
+    # forces the integrator holds = cached + restraints of the start geometry (tether at x0 gives zero there)
+    _, F_r = hookean_forces(torch.as_tensor(pos, dtype=torch.float64), cons)
+    np.testing.assert_allclose(md.F.cpu().numpy(), keep.cpu().numpy() + F_r.numpy(), rtol=0, atol=2e-5)
+    for _ in range(5):
+        md.step()
+    torch.cuda.synchronize()
+    assert torch.equal(cached, keep)

@@ -167,3 +167,97 @@ def test_dl_bonded_calculator_reference_constructor_and_call(model, tmp_path):
     mm.set_parameters(prot)
     e_mm, f_mm = mm(prot)
     assert np.isfinite(e_mm) and f_mm.shape == (len(prot), 3) and np.abs(f_mm.sum(0)).max() < 1e-3
+
+
+def _fragment_pool():
+    """the 220 DISTINCT fragments of the four example proteins with their reference-source results (placed caps)"""
+    pool = []
+    for pname in PROTEINS:
+        g = load(pname)
+        ib = 0
+        for b in range(len(g["start"])):
+            a0, a1 = int(g["start"][b]), int(g["end"][b])
+            if a1 == a0:
+                continue
+            pool.append((g["z"][a0:a1], g["pos_placed"][a0:a1], g["E_ref64_placed"][ib], g["F_ref64_placed"][a0:a1],
+                         g["F_ref32_placed"][a0:a1]))
+            ib += 1
+    return pool
+
+
+@pytest.mark.parametrize("layout", ["golden_first", "golden_across_a_chunk_cut"])
+def test_heterogeneous_4096_fragment_batch_against_reference_goldens(model, layout):
+    """bench.py's fragment batch as a test: 4096 fragments cycling through the 220 distinct ones, ONE block of 220 at
+    the golden geometry (reference-source E / F known), the rest jittered by 0.05 A - every fragment of the block is
+    checked, through the fused panel products (`fuse_panel` 1) and the plain path (0).  Second layout: the workspace
+    bound (`max_chunk_edges`) is lowered so that the batch runs as several chunks of >= 4096 atoms each and the first
+    chunk boundary CUTS THROUGH the golden block (ragged last panels on one side, a fresh graph on the other)."""
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+
+    pool = _fragment_pool()
+    assert len(pool) == 220
+    nf = 4096
+    rng = np.random.default_rng(99)
+    sizes_cycle = np.asarray([len(pool[i % 220][0]) for i in range(nf)])
+    mnb = 32
+    slots = np.cumsum(sizes_cycle * np.minimum(sizes_cycle, mnb))
+    if layout == "golden_first":
+        off, chunk = 0, None
+    else:
+        chunk = 300_000                                   # ~ 12.8 k atoms per chunk: still the batch regime (N >= 4096)
+        cut = int(np.searchsorted(slots, chunk, side="right"))   # first fragment of the second chunk (greedy rule)
+        off = (cut - 110) // 220 * 220                    # a whole number of cycles, so block member i is pool[i]
+        assert off <= cut - 30 and off + 220 >= cut + 30, (off, cut)
+    zs, ps = [], []
+    for i in range(nf):
+        zf, pf = pool[i % 220][:2]
+        zs.append(zf)
+        ps.append(pf if off <= i < off + 220 else pf - pf.mean(0) + rng.normal(0, 0.05, size=pf.shape))
+    end = np.cumsum(sizes_cycle)
+    start = end - sizes_cycle
+    z = np.concatenate(zs)
+    pos = np.concatenate(ps).astype(np.float32)
+    fd = FragmentData(z, pos, start, end, make_batch_index(start, end))
+    a0, a1 = int(start[off]), int(end[off + 219])
+    E64 = np.concatenate([np.atleast_1d(p[2]).reshape(-1) for p in pool]).reshape(-1, 1)
+    F64 = np.concatenate([p[3] for p in pool])
+    F32 = np.concatenate([p[4] for p in pool])
+    eng = model.engine
+    ref = None
+    try:
+        if chunk:
+            eng.set_option("max_chunk_edges", chunk)
+        for fuse in (1, 0):
+            eng.set_option("fuse_panel", fuse)
+            e, f = model.dl_potential_loader(fd)
+            check(e[off:off + 220], f[a0:a1], E64, F64, F32)
+            if ref is None:
+                ref = (e, f)
+            else:  # the switch changes the schedule, not the result beyond fp32 round-off
+                np.testing.assert_allclose(e, ref[0], rtol=0, atol=2e-5)
+                np.testing.assert_allclose(f, ref[1], rtol=0, atol=2e-5)
+        if chunk:  # chunking itself: the same batch as ONE chunk gives the same numbers
+            eng.set_option("max_chunk_edges", 1310720)
+            eng.set_option("fuse_panel", 1)
+            e1, f1 = model.dl_potential_loader(fd)
+            np.testing.assert_allclose(e1, ref[0], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(f1, ref[1], rtol=0, atol=2e-5)
+    finally:
+        eng.set_option("max_chunk_edges", 1310720)
+        eng.set_option("fuse_panel", 1)
+
+
+def test_panel_path_forced_at_single_protein_size_matches_golden(model):
+    """`panel_min_edges = 0` sends a single protein (Trp-cage, N = 737: 12 ragged 64-row panels per 737 nodes) through
+    the fused panel products that normally only batches take - same reference-source golden, same tolerance."""
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+
+    g = load("trpcage")
+    fd = FragmentData(g["z"], g["pos_relaxed"], g["start"], g["end"], make_batch_index(g["start"], g["end"]))
+    eng = model.engine
+    try:
+        eng.set_option("panel_min_edges", 0)
+        e, f = model.dl_potential_loader(fd)
+    finally:
+        eng.set_option("panel_min_edges", 1 << 40)
+    check(e, f, g["E_ref64_relaxed"], g["F_ref64_relaxed"], g["F_ref32_relaxed"])

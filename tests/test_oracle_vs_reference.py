@@ -294,3 +294,49 @@ def test_hparams_are_recovered_from_a_reference_module():
         ours = set(make_state_dict(hp, seed=1).keys())
         theirs = set(model.state_dict().keys())
         assert ours == theirs, ours ^ theirs
+
+
+def test_compiled_reference_recipe_gives_the_source_results_bit_for_bit():
+    """oracle/make_ref.py (run by __graft_entry__.build()): the reference's model package byte-compiled into the
+    git-ignored oracle/_ref/ is what bench.py's cpu_baseline leg imports on the GPU box, where /root/reference does not
+    exist.  Same interpreter, same code objects: energies and forces equal the source tree's to the last bit, and no
+    .py file of the reference lands in the repository."""
+    import os
+    import subprocess
+    import sys
+
+    from oracle import make_ref
+    from oracle.ref_import import COMPILED_REF, compiled_reference_available
+
+    out = make_ref.build()
+    assert out == COMPILED_REF and compiled_reference_available()
+    for d, _, files in os.walk(COMPILED_REF):
+        assert not [f for f in files if f.endswith(".py")], "reference sources must not be copied"
+    # a fresh interpreter per origin: the two packages share the module name `ViSNet`
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle.ref_import import import_reference_create_model
+from oracle.weights import default_hparams, make_state_dict
+from oracle.inputs import random_fragments
+create_model = import_reference_create_model(prefer=sys.argv[1])
+import ViSNet
+assert (sys.argv[1] == "compiled") == ("_ref" in ViSNet.__path__[0]), ViSNet.__path__
+hp = default_hparams(embedding_dimension=64, num_layers=2)
+m = create_model(hp)
+m.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in make_state_dict(hp, seed=3).items()})
+m = m.float().eval()
+z, pos, start, end = random_fragments(8, [22, 12, 30])
+batch = np.repeat(np.arange(3), [22, 12, 30])
+E, F = m(dict(z=torch.as_tensor(z), pos=torch.as_tensor(pos), batch=torch.as_tensor(batch)))
+np.save(sys.argv[2], np.concatenate([E.detach().numpy().ravel(), F.detach().numpy().ravel()]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for origin in ("source", "compiled"):
+            f = os.path.join(td, origin + ".npy")
+            subprocess.run([sys.executable, "-c", code, origin, f], check=True, timeout=300)
+            res[origin] = np.load(f)
+    assert np.array_equal(res["source"], res["compiled"])
