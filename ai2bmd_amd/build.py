@@ -18,7 +18,11 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvsn_hip.so")
 SOURCES = ["gemm.hip", "graph.hip", "layer_fwd.hip", "layer_bwd.hip", "fused.hip", "vecnorm.hip", "head.hip", "head_fused.hip", "md.hip", "mm.hip", "hydrogen.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", "pgemm.h", "tail.h", os.path.join("..", "..", "include", "vsn.h")]
+HEADERS = ["common.h", "kernels.h", "pgemm.h", "gemm_s3.h", "tail.h", os.path.join("..", "..", "include", "vsn.h")]
+# md.hip holds every kernel whose per-atom arithmetic is shared between two launches (the step ends stand-alone and
+# fused with the integrator halves, csrc/tail.h): contraction is off for the whole file, so bit-identity between those
+# launches does not hang on per-function pragmas
+PER_FILE_FLAGS = {"md.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -35,6 +39,7 @@ def _digest() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -48,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     def cc(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -124,6 +124,8 @@ struct vsn_ctx {
   bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
   bool fuse_panel = true;  // fragment batches, hidden 256: gather kernels as prologues of panel GEMMs (fused.hip)
   int64_t panel_min_edges = (int64_t)1 << 40;  // ... and below the batch regime from this many edge slots on (A/B aid: off)
+  bool gemm_split3 = false;   // opt-in: grouped products as 3 x bf16 split MFMA products (gemm_s3.h); default fp32 MFMA
+  Split3Table* s3 = nullptr;  // ... and the packed bf16 planes of this engine's weights (made on first use)
   // debug snapshots: name -> per-layer device copies
   std::map<std::string, std::vector<float*>> snap;
   std::map<std::string, size_t> snap_elems;
@@ -191,6 +193,7 @@ extern "C" void vsn_destroy(vsn_handle c) {
   hipSetDevice(c->device);
   if (c->warena) hipFree(c->warena);
   if (c->ws.base) hipFree(c->ws.base);
+  split3_table_destroy(c->s3);
   if (c->side) hipStreamDestroy(c->side);
   if (c->ev_fork) hipEventDestroy(c->ev_fork);
   if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -240,6 +243,11 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->fuse_panel = value != 0;
   } else if (k == "panel_min_edges") {
     c->panel_min_edges = value;
+  } else if (k == "gemm_split3") {
+    // opt-in arithmetic mode (default 0 = fp32 MFMA everywhere): the grouped products of single-protein sizes as
+    // 3 x bf16 split products with fp32 accumulation (gemm_s3.h).  Plain launches (batches, read-out) stay fp32.
+    c->gemm_split3 = value != 0;
+    if (c->gemm_split3 && !c->s3) c->s3 = split3_table_create();
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -1180,10 +1188,12 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
       return rc0;
     }
     set_gemm_splitk_workspace(c->splitk, c->splitk_elems);
+    set_gemm_split3(c->gemm_split3 ? c->s3 : nullptr);
     int rc = run_chunk(c, st, dev_z + a0, dev_pos + 3 * a0, fs, fe, (int)(a1 - a0), (int)(b1 - b0), (int)eb,
                        (int)maxfrag, dev_e_out + b0, dev_f_out + 3 * a0);
     set_gemm_profiler(nullptr);
     set_gemm_splitk_workspace(nullptr, 0);
+    set_gemm_split3(nullptr);
     if (c->profile) {
       hipStreamSynchronize(st);
       int E = 0;

@@ -21,6 +21,7 @@
 // 32-63 take k0+4..k0+7; MFMA #t pairs (k0+t, k0+4+t) for A and B alike, so
 // the k-sum is just reordered.
 #include <cstdlib>
+#include <map>
 #include <type_traits>
 
 #include "common.h"
@@ -314,6 +315,8 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
 #undef VSN_LDS_AT
 }
 
+#include "gemm_s3.h"  // opt-in 3 x bf16 split form of the grouped 64 x 64 tile (gemm_body3, Split3Table)
+
 template <int BM, int BN, int WM, int WN, bool DB, int SILU = 0, int BK = 32>
 __global__ __launch_bounds__(WM * WN * 64) void k_gemm(const float* __restrict__ A, int lda,
                                               const float* __restrict__ Bt, int ldb,
@@ -339,8 +342,12 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
       p = q + 1;
     }
   const GemmDesc& d = g.p[p];
-  gemm_body<64, 64, 2, 2, true, 0, 32>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
-                                           d.flags, d.ksplit, d.part, b, smem);
+  if (d.flags & VSN_S3_FLAG)  // opt-in mode gemm_split3: this member's weight operand is its packed bf16 planes
+    gemm_body3(d.A, d.lda, reinterpret_cast<const unsigned short*>(d.Bt), d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc,
+               d.K, d.flags, d.ksplit, d.part, b, smem);
+  else
+    gemm_body<64, 64, 2, 2, true, 0, 32>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
+                                         d.flags, d.ksplit, d.part, b, smem);
 }
 
 // split-K epilogue: C (+)= sum_s part[s] (+ bias), fixed summation order
@@ -580,6 +587,7 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
   for (int i = 0; i < n; ++i) {
     GemmDesc d = descs[i];
     if (d.M <= 0) continue;
+    s3_patch(d, st);
     const int t = ((d.M + 63) / 64) * (d.Nc / 64);
     int ks = 1;
     if (d.keep_parts > 1) {

@@ -8,7 +8,6 @@
 // elementwise glue here is N-sized (negligible next to the E-sized layer work).
 #include "common.h"
 #include "kernels.h"
-#include "tail.h"
 
 namespace vsn {
 
@@ -179,50 +178,6 @@ int launch_head_backward(hipStream_t st, const Dims& D, const HeadW& W, const He
                      Bf.cat0, 2 * H, H, Bf.pv0, ldp, Bf.g_pv0, ldp);
   rc |= launch_gemm(st, Bf.g_pv0, ldp, W.Wpv0T, ldp, g_vo, H, nullptr, N * S, nullptr, H, ldp, 0);
   return rc;
-}
-
-// ---- overlap-force recombination (Calculators/combiner.py:38-39) ----------------
-// f_prot[a] = sum_{k in [off[a], off[a+1])} sign[k] * f_frag[rows[k]]   (fixed order)
-// optionally also E = sum_k e_sign[k] * buf[e_idx[k]] (combiner.py:19), reduced by the first wave in a fixed order
-__global__ void k_combine(int n_prot, const int* __restrict__ off, const int* __restrict__ rows,
-                          const float* __restrict__ sign, const float* __restrict__ f_frag,
-                          float* __restrict__ f_prot, int n_e, const int* __restrict__ e_idx,
-                          const float* __restrict__ e_sign, float* __restrict__ e_out) {
-  if (e_out && blockIdx.x == 0 && threadIdx.x < 64) {
-    const float s = combine_energy_wave((int)threadIdx.x, n_e, e_idx, e_sign, f_frag);
-    if (threadIdx.x == 0) *e_out = s;
-  }
-  const int a = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a >= n_prot) return;
-  float fx, fy, fz;
-  combine_atom(a, off, rows, sign, f_frag, fx, fy, fz);
-  f_prot[3 * (size_t)a + 0] = fx;
-  f_prot[3 * (size_t)a + 1] = fy;
-  f_prot[3 * (size_t)a + 2] = fz;
-}
-
-int launch_combine(hipStream_t st, int n_prot, const int* off, const int* rows, const float* sign,
-                   const float* f_frag, float* f_prot, int n_e, const int* e_idx, const float* e_sign, float* e_out) {
-  if (n_prot <= 0) return 0;
-  hipLaunchKernelGGL(k_combine, dim3(nblk(n_prot)), dim3(256), 0, st, n_prot, off, rows, sign, f_frag, f_prot, n_e,
-                     e_idx, e_sign, e_out);
-  return 0;
-}
-
-// ---- per-step fragment geometry (distancefrag.py:35-54): gather + cap hydrogens ---------
-__global__ void k_build_fragments(int n, const int* __restrict__ src, const int* __restrict__ acc,
-                                  const int* __restrict__ tow, const float* __restrict__ len,
-                                  const float* __restrict__ prot, float* __restrict__ out) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  build_row(k, src, acc, tow, len, prot, out);
-}
-
-int launch_build_fragments(hipStream_t st, int n, const int* src, const int* acc, const int* tow, const float* len,
-                           const float* prot, float* out) {
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_build_fragments, dim3(nblk(n)), dim3(256), 0, st, n, src, acc, tow, len, prot, out);
-  return 0;
 }
 
 }  // namespace vsn

@@ -116,6 +116,12 @@ struct LaunchEvents {
 };
 void set_launch_events(const LaunchEvents* ev);  // thread-local; consumed by that launch
 void set_gemm_splitk_workspace(float* p, size_t elems);  // thread-local scratch for split-K partials
+// opt-in product mode gemm_split3 (gemm_s3.h): the grouped launches of this thread run their members as 3 x bf16 split
+// products while a table is set; the table caches the packed weight planes of one engine
+struct Split3Table;
+Split3Table* split3_table_create();
+void split3_table_destroy(Split3Table* t);
+void set_gemm_split3(Split3Table* t);  // thread-local; nullptr (default) = fp32 MFMA products
 
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);

@@ -206,8 +206,8 @@ def test_heterogeneous_4096_fragment_batch_against_reference_goldens(model, layo
     else:
         chunk = 300_000                                   # ~ 12.8 k atoms per chunk: still the batch regime (N >= 4096)
         cut = int(np.searchsorted(slots, chunk, side="right"))   # first fragment of the second chunk (greedy rule)
-        off = (cut - 110) // 220 * 220                    # a whole number of cycles, so block member i is pool[i]
-        assert off <= cut - 30 and off + 220 >= cut + 30, (off, cut)
+        off = cut - 110                                   # the cut falls in the middle of the golden block
+        assert off > 220 and off + 220 < nf
     zs, ps = [], []
     for i in range(nf):
         zf, pf = pool[i % 220][:2]
@@ -219,9 +219,10 @@ def test_heterogeneous_4096_fragment_batch_against_reference_goldens(model, layo
     pos = np.concatenate(ps).astype(np.float32)
     fd = FragmentData(z, pos, start, end, make_batch_index(start, end))
     a0, a1 = int(start[off]), int(end[off + 219])
-    E64 = np.concatenate([np.atleast_1d(p[2]).reshape(-1) for p in pool]).reshape(-1, 1)
-    F64 = np.concatenate([p[3] for p in pool])
-    F32 = np.concatenate([p[4] for p in pool])
+    block = [pool[i % 220] for i in range(off, off + 220)]  # batch position i holds pool[i % 220]
+    E64 = np.concatenate([np.atleast_1d(p[2]).reshape(-1) for p in block]).reshape(-1, 1)
+    F64 = np.concatenate([p[3] for p in block])
+    F32 = np.concatenate([p[4] for p in block])
     eng = model.engine
     ref = None
     try:
