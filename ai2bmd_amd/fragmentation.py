@@ -231,6 +231,43 @@ def build_plan(p: ProteinAtoms) -> FragmentPlan:
     )
 
 
+_GREEK = {c: i for i, c in enumerate("ABGDEZH")}
+
+
+def preprocessed_order(p: ProteinAtoms) -> ProteinAtoms:
+    """The protein with the atoms of every residue in the order the reference's OWN fragmenter requires of its input:
+    what its preprocessing leaves behind (Tinker `xyzpdb` output passed through `reorder_atoms`,
+    /root/reference/src/utils/pdb.py:42-100) - backbone N CA C O H HA[2,3], then the side-chain heavy atoms by
+    Greek position (B G D E Z H) and branch number, then the side-chain hydrogens in the same order; caps as
+    `CH3 C O H1 H2 H3` / `N CH3 H HH31 HH32 HH33`.  The reference permutes its rows with tables that assume this order
+    (utils/seq_dict.pkl, distancefrag.py:507-738); `build_plan` matches atoms by NAME and takes any order, so this
+    is only needed to hand a protein to the reference (oracle/ref_fragmenter.py) or to write a PDB it can read.
+    The rule reproduces the reference's pre-processed Chignolin example atom for atom and, on Trp-cage / WW / ABD,
+    makes the reference's fragmenter agree with `amber_ordered(build_plan(.))` row for row
+    (tests/test_fragmentation_and_sharding.py)."""
+    def key(name):
+        body = name[1:]
+        return (name.startswith("H"), _GREEK.get(body[:1], 99), body[1:])
+
+    rows = []
+    for r in sorted(set(p.resnums.tolist())):
+        idx = np.flatnonzero(p.resnums == r)
+        nm = [str(x) for x in p.names[idx]]
+        rn = str(p.resnames[idx[0]])
+        if rn == "ACE":
+            want = ["CH3", "C", "O", "H1", "H2", "H3"]
+        elif rn == "NME":
+            want = ["N", "CH3", "H", "HH31", "HH32", "HH33"]
+        else:
+            bb = [x for x in ("N", "CA", "C", "O", "H", "HA", "HA2", "HA3") if x in nm]
+            want = bb + sorted((x for x in nm if x not in bb), key=key)
+        if sorted(want) != sorted(nm):
+            raise ValueError(f"residue {r} ({rn}): unexpected atom names {nm}")
+        rows += [int(idx[nm.index(w)]) for w in want]
+    rows = np.asarray(rows)
+    return ProteinAtoms(p.names[rows], p.resnames[rows], p.resnums[rows], p.numbers[rows], p.positions[rows])
+
+
 def fragment_positions(plan: FragmentPlan, prot_pos: np.ndarray) -> np.ndarray:
     """Host (numpy) evaluation of the per-step fragment geometry - used by tests and
     fixtures; the product path runs the same arithmetic in `vsn_build_fragments`."""

@@ -51,13 +51,19 @@ def chig_with_disulfide(p):
 
 
 def main():
-    # only the PRE-PROCESSED example: the reference's permutation tables (utils/seq_dict.pkl) assume the atom order its
-    # own preprocessing (external AmberTools) writes; on the raw examples/*.pdb its fragmenter pairs atomic numbers
-    # with the wrong rows.  Chignolin covers TYR ASP PRO GLU THR GLY TRP incl. the PRO / GLY neighbour special cases.
-    for name in ("chig", "chigcyx"):
-        z = np.load(os.path.join(ROOT, "tests", "golden", "protein_chig.npz"))
+    # The reference's permutation tables (utils/seq_dict.pkl) assume the atom order its own preprocessing leaves
+    # behind (Tinker xyzpdb + utils/pdb.py:reorder_atoms); on the raw examples/*.pdb (tleap order) its fragmenter
+    # pairs atomic numbers with the wrong rows.  "chig" is the reference's pre-processed example as it is; the other
+    # three examples are put into that order by ai2bmd_amd.fragmentation.preprocessed_order (which reproduces the
+    # pre-processed Chignolin file atom for atom) - the C3 / C4 inputs of BASELINE.json.
+    for name in ("chig", "chigcyx", "trpcage", "ww", "abd"):
+        z = np.load(os.path.join(ROOT, "tests", "golden", f"protein_{'chig' if name.startswith('chig') else name}.npz"))
         p = ProteinAtoms(names=z["names"], resnames=z["resnames"], resnums=z["resnums"], numbers=z["numbers"],
                          positions=z["positions"])
+        if not name.startswith("chig"):
+            from ai2bmd_amd.fragmentation import preprocessed_order
+
+            p = preprocessed_order(p)
         if name == "chigcyx":
             p = chig_with_disulfide(p)
             np.savez_compressed(os.path.join(ROOT, "tests", "golden", "protein_chigcyx.npz"), names=p.names,

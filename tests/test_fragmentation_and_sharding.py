@@ -229,7 +229,26 @@ def _row_permutation(plan, prot_pos, ref):
     return perm
 
 
-@pytest.mark.parametrize("name", ["chig", "chigcyx"])
+def load_for_reference(name):
+    """the protein in the atom order the reference's fragmenter was run on (oracle/make_fragmenter_golden.py): the
+    pre-processed Chignolin example as it is, the other examples through preprocessed_order"""
+    from ai2bmd_amd.fragmentation import preprocessed_order
+
+    prot = load_protein(name)
+    return prot if name.startswith("chig") else preprocessed_order(prot)
+
+
+def test_preprocessed_order_reproduces_the_reference_example():
+    from ai2bmd_amd.fragmentation import preprocessed_order
+
+    prot = load_protein("chig")  # = examples/chig_preprocessed/chig-preeq-nowat.pdb
+    again = preprocessed_order(prot)
+    assert np.array_equal(again.names, prot.names) and np.array_equal(again.positions, prot.positions)
+    shuffled = load_protein("trpcage")  # tleap order: a different one
+    assert not np.array_equal(preprocessed_order(shuffled).names, shuffled.names)
+
+
+@pytest.mark.parametrize("name", ["chig", "chigcyx", "trpcage", "ww", "abd"])
 def test_plan_matches_reference_fragmenter(name):
     """golden = the reference's own DistanceFragment.fragment + get_dipeptide_positions (oracle/ref_fragmenter.py) on
     its pre-processed Chignolin example: same fragments, same atoms, same cap-hydrogen first-guess positions, same
@@ -238,7 +257,7 @@ def test_plan_matches_reference_fragmenter(name):
     dipeptides are merged into one 44-atom fragment and the second slot stays empty."""
     from ai2bmd_amd.fragmentation import build_plan, combine_host
 
-    prot = load_protein(name)
+    prot = load_for_reference(name)
     plan = build_plan(prot)
     ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
     assert np.array_equal(plan.start, ref["start"]) and np.array_equal(plan.end, ref["end"])
@@ -265,7 +284,7 @@ def test_plan_matches_reference_fragmenter(name):
     np.testing.assert_allclose(F_mine, F_ref, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["chig", "chigcyx"])
+@pytest.mark.parametrize("name", ["chig", "chigcyx", "trpcage", "ww", "abd"])
 def test_amber_ordered_plan_is_row_identical_to_the_reference(name):
     """ai2bmd_amd.hydrogen.amber_ordered: a FragmentData built from it equals, row for row, what the reference's
     DistanceFragment produces - atomic numbers, first-guess positions, select/origin indices."""
@@ -273,7 +292,7 @@ def test_amber_ordered_plan_is_row_identical_to_the_reference(name):
     from ai2bmd_amd.fragmentation import build_plan, fragment_positions
     from ai2bmd_amd.hydrogen import amber_ordered
 
-    prot = load_protein(name)
+    prot = load_for_reference(name)
     plan = amber_ordered(prot, build_plan(prot), load_tables(os.path.join(GOLDEN, "amber_tables.npz")))
     ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
     assert np.array_equal(plan.z, ref["z"])

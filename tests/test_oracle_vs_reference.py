@@ -122,17 +122,20 @@ def test_live_reference_fragment_data():
         assert len(m) == len(r)
 
 
-def test_live_reference_fragmenter_matches_golden():
-    """the committed golden of the reference's fragmenter is what the reference tree produces now"""
+@pytest.mark.parametrize("name", ["chig", "trpcage", "ww", "abd"])
+def test_live_reference_fragmenter_matches_golden(name):
+    """the committed golden of the reference's fragmenter is what the reference tree produces now (Chignolin: the
+    reference's pre-processed example; the C3 / C4 proteins: its examples put into that atom order)"""
     import os
 
-    from ai2bmd_amd.fragmentation import ProteinAtoms
+    from ai2bmd_amd.fragmentation import ProteinAtoms, preprocessed_order
     from conftest import GOLDEN
     from oracle.ref_fragmenter import run_reference_fragmenter
 
-    d = np.load(os.path.join(GOLDEN, "protein_chig.npz"))
-    r = run_reference_fragmenter(ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"]))
-    g = np.load(os.path.join(GOLDEN, "fragref_chig.npz"))
+    d = np.load(os.path.join(GOLDEN, f"protein_{name}.npz"))
+    p = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"])
+    r = run_reference_fragmenter(p if name == "chig" else preprocessed_order(p))
+    g = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
     assert np.array_equal(r["z"], g["z"]) and np.array_equal(r["select_index"], g["select_index"])
     assert np.array_equal(r["origin_index"], g["origin_index"]) and np.allclose(r["pos"], g["pos"], atol=1e-6)
 
