@@ -259,14 +259,22 @@ static const bool g_fused_env = [] {
 
 bool panel_ok(const Dims& D) { return g_fuse_panel && D.H == 256 && D.S == 8 && D.nh >= 2 && D.nh <= 64; }
 
+// the attribute is per DEVICE: remembered per (current device, kernel), so a thread that drives engines on several
+// GPUs sets it on each of them
 template <typename K>
 static inline void panel_lds(K kern) {
-  static thread_local const void* done[16];
+  struct Key {
+    int dev;
+    const void* k;
+  };
+  static thread_local Key done[64];
   static thread_local int ndone = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   for (int i = 0; i < ndone; ++i)
-    if (done[i] == (const void*)kern) return;
+    if (done[i].dev == dev && done[i].k == (const void*)kern) return;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-  if (ndone < 16) done[ndone++] = (const void*)kern;
+  if (ndone < 64) done[ndone++] = Key{dev, (const void*)kern};
 }
 
 int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,

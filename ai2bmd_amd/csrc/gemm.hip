@@ -506,6 +506,13 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
   }
   float* part = ks > 1 ? tl_splitk_ws : nullptr;
   const int grid = tiles * ks;
+  if (variant == 0 && ks == 1 && tl_s3) {  // opt-in mode gemm_split3: the batch tile as 3 x bf16 split products
+    if (const unsigned short* pl = s3_planes(Bt, ldb, Nc, K, flags, st)) {
+      hipLaunchKernelGGL(k_gemm3_128, dim3(grid), dim3(256), 0, st, A, lda, pl, ldb, C, ldc, bias, M, Mptr, Nc, K,
+                         flags);
+      return 0;
+    }
+  }
   if (variant == 0) {
     if (g_gemm_db128) hipLaunchKernelGGL((k_gemm<128, 128, 2, 2, true>), dim3(grid), dim3(256), 0, st, A, lda, Bt, ldb, C, ldc, bias, M,
                        Mptr, Nc, K, flags, ks, part);

@@ -157,6 +157,125 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     if ((r & 3) + 8 * (r >> 2) < rlim) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[r] + bv;
 }
 
+// The batch tile in the same mode: 128 x 128 per workgroup, 4 waves (2 x 2, 64 x 64 each = 2 x 2 MFMA tiles), BK = 32,
+// one LDS stage of six planes (48 KiB) + register prefetch of the next k-tile.  The weight planes come from the SAME
+// fragment-ordered packing as above (thread (row lr, k-half lh) picks its two 16-byte pieces of a 16-k block).
+// byte offset of 16-byte chunk c of row r in a 128-row x 64-byte plane
+__device__ __forceinline__ int s3_at128(int r, int c) { return r * 64 + ((c ^ ((r >> 1) & 3)) << 4); }
+__global__ __launch_bounds__(256) void k_gemm3_128(const float* __restrict__ A, int lda,
+                                                   const unsigned short* __restrict__ B3, int ldb,
+                                                   float* __restrict__ C, int ldc, const float* __restrict__ bias, int M,
+                                                   const int* __restrict__ Mptr, int Nc, int K, int flags) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[6 * 8192];
+  unsigned char* const lA = lds;
+  unsigned char* const lB = lds + 3 * 8192;
+  int Meff = M;
+  if (Mptr) {
+    int md = *Mptr;
+    Meff = md < M ? md : M;
+  }
+  const int tiles_n = Nc / 128;
+  const int live = ((Meff + 127) / 128) * tiles_n;
+  if ((int)blockIdx.x >= live) return;
+  const int bid = VSN_XCD_REMAP ? xcd_block((int)blockIdx.x, live) : (int)blockIdx.x;
+  const int tm = bid / tiles_n, tn = bid % tiles_n;
+  const int row0 = tm * 128, col0 = tn * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi5 = lane >> 5;
+  // staging role: row lr of the tile, k-half lh (16 k-values = chunks 2 lh, 2 lh + 1)
+  const int lr = tid >> 1, lh = tid & 1;
+  const int ar = row0 + lr < Meff ? row0 + lr : Meff - 1;  // rows past Meff repeat the last row; never stored
+  const float* __restrict__ ag = A + (size_t)ar * lda + lh * 16;
+  const int n = col0 + lr;
+  // 16-k block kb of column n, plane p, k-half c: (((n >> 5) * (ldb >> 4) + kb) * 3 + p) * 64 + (n & 31) + 32 c  (x 8 bf16)
+  const unsigned short* __restrict__ bg = B3 + ((((size_t)(n >> 5) * (size_t)(ldb >> 4) + lh) * 3) * 64 + (n & 31)) * 8;
+  f32x4 ra[4];
+  s3_bf16x8 rb[3][2];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const f32x4*>(ag + kt * 32 + q * 4);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        rb[p][c] = *reinterpret_cast<const s3_bf16x8*>(bg + (((size_t)kt * 2 * 3 + p) * 64 + 32 * c) * 8);
+  };
+  auto sstore = [&]() {
+    s3_bf16x8 rap[3][2];
+    s3_split8(ra[0], ra[1], rap[0][0], rap[1][0], rap[2][0]);
+    s3_split8(ra[2], ra[3], rap[0][1], rap[1][1], rap[2][1]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        *reinterpret_cast<s3_bf16x8*>(lA + p * 8192 + s3_at128(lr, 2 * lh + c)) = rap[p][c];
+        *reinterpret_cast<s3_bf16x8*>(lB + p * 8192 + s3_at128(lr, 2 * lh + c)) = rb[p][c];
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nkt = K / 32;
+  gload(0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    __syncthreads();  // the previous stage's fragments are consumed
+    sstore();
+    __syncthreads();
+    if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const int c = kc * 2 + hi5;
+      s3_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const s3_bf16x8*>(lA + p * 8192 + s3_at128(r, c));
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = wn * 64 + j * 32 + l31;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const s3_bf16x8*>(lB + p * 8192 + s3_at128(r, c));
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {  // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  const bool rmw = (flags & 1) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + wn * 64 + j * 32 + l31;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + wm * 64 + i * 32 + 4 * hi5 + (r & 3) + 8 * (r >> 2);
+        if (row < Meff) {
+          float* cp = C + (size_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (rmw) v += *cp;
+          *cp = v;
+        }
+      }
+    }
+}
+
 // W [Nc][ldb] fp32 -> packed planes (hi, mid, lo) in fragment order
 __global__ void k_s3_pack(const float* __restrict__ W, size_t n, int ldb, unsigned short* __restrict__ out) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,23 +309,30 @@ void split3_table_destroy(Split3Table* t) {
 static thread_local Split3Table* tl_s3 = nullptr;
 void set_gemm_split3(Split3Table* t) { tl_s3 = t; }
 
-// swap a member's weight operand for its planes and mark it (members the split tile does not cover stay fp32)
-static void s3_patch(GemmDesc& d, hipStream_t st) {
-  if (!tl_s3 || (d.flags & 2) || (d.ldb & 15) || (d.K & 31) || (d.Nc & 63)) return;
+// the packed planes of a weight operand [Nc][ldb] of which a product reads K columns (made on first sight, on the
+// launch stream); nullptr where the split tiles do not apply
+static const unsigned short* s3_planes(const float* Bt, int ldb, int Nc, int K, int flags, hipStream_t st) {
+  if (!tl_s3 || (flags & 2) || (ldb & 15) || (K & 31) || (Nc & 63)) return nullptr;
   // the operand may be a K-window of a wider matrix (ldb > K): only what the product reads is read here
-  const size_t elems = (size_t)(d.Nc - 1) * d.ldb + d.K;
-  auto it = tl_s3->cache.find(d.Bt);
+  const size_t elems = (size_t)(Nc - 1) * ldb + K;
+  auto it = tl_s3->cache.find(Bt);
   if (it == tl_s3->cache.end() || it->second.elems < elems) {
     unsigned short* p = nullptr;
-    if (hipMalloc((void**)&p, 3 * (size_t)d.Nc * d.ldb * sizeof(unsigned short)) != hipSuccess) return;
-    hipLaunchKernelGGL(k_s3_pack, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, d.Bt, elems, d.ldb, p);
+    if (hipMalloc((void**)&p, 3 * (size_t)Nc * ldb * sizeof(unsigned short)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(k_s3_pack, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, Bt, elems, ldb, p);
     if (it != tl_s3->cache.end()) {
       hipStreamSynchronize(st);  // (a smaller view of the same operand was cached: its users are done before it goes)
       hipFree(it->second.planes);
     }
-    tl_s3->cache[d.Bt] = Split3Table::Entry{p, elems};
-    it = tl_s3->cache.find(d.Bt);
+    tl_s3->cache[Bt] = Split3Table::Entry{p, elems};
+    it = tl_s3->cache.find(Bt);
   }
-  d.Bt = reinterpret_cast<const float*>(it->second.planes);
+  return it->second.planes;
+}
+// swap a grouped member's weight operand for its planes and mark it (members the split tile does not cover stay fp32)
+static void s3_patch(GemmDesc& d, hipStream_t st) {
+  const unsigned short* pl = s3_planes(d.Bt, d.ldb, d.Nc, d.K, d.flags, st);
+  if (!pl) return;
+  d.Bt = reinterpret_cast<const float*>(pl);
   d.flags |= VSN_S3_FLAG;
 }

@@ -462,6 +462,11 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims 
   }
 }
 
+// (Round 4: an S-SPLIT form of this kernel at single-protein sizes - waves own the spherical components instead of
+//  splitting the edges, the activations of an edge staged through LDS once, four vh rows in flight, no cross-wave
+//  reduction - measured 14.4-14.5 us against 13.8-14.0 us for the form above, Chignolin 447.8-448.5 vs 448.8-449.0
+//  steps/s, and was removed: LAB_NOTES.md section 11.)
+
 // ---- edge update (visnet_block.py:290-295): f_e += silu(pf_e) * <rej(wt_i,d), rej(ws_j,d)> ---
 // <w1,w2> = u1.u2 + (u1.d)(u2.d)(|d|^2 - 2)   (expanded double rejection)
 template <int V, int S, int WPN, bool GEN>

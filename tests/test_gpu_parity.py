@@ -438,6 +438,31 @@ def test_visnet_model_positional_device_like_the_reference(lib_built, tmp_path):
     check(e, f, g["E_ref64"], g["F_ref64"])
 
 
+@pytest.mark.parametrize("nh", [2, 4, 16, 32, 64])
+def test_batch_path_other_head_counts(lib_built, nh):
+    """the fused panel products (fused.hip: panel_ok admits 2..64 heads at hidden 256) with every head count besides
+    the default 8: the per-head lane arithmetic of k_bwd_gf_fused / k_bwd_attn_Q (64 / nh lanes per head, group sums
+    over 32 lanes at nh = 2, one lane per head at nh = 64) against the fp64 oracle, fused and unfused"""
+    hp = default_hparams(embedding_dimension=256, num_layers=2, num_heads=nh)
+    z1, p1, s1, e1 = random_fragments(16, [22, 12, 36])
+    reps = 60
+    n1 = len(z1)
+    z = np.tile(z1, reps)
+    pos = np.tile(p1, (reps, 1))
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    assert len(z) >= 4096
+    m = model_for(hp, 9)
+    E64, F64, _ = ViSNetOracle(hp, make_state_dict(hp, seed=9), torch.float64).energy_forces(z1, p1, s1, e1)
+    try:
+        for fuse in (1, 0):
+            m.engine.set_option("fuse_panel", fuse)
+            e, f = m.dl_potential_loader(frag(z, pos, start, end))
+            check(e.reshape(reps, -1)[0].reshape(-1, 1), f.reshape(reps, n1, 3)[0], E64, F64)
+    finally:
+        m.engine.set_option("fuse_panel", 1)
+
+
 @pytest.mark.parametrize("acts", [None, ("ssp", "tanh")])
 def test_batch_path_option_matrix(lib_built, acts):
     """Fragment batch (N >= 4096, hidden 256: one wave per node, panel / fused products): the A/B switches of the

@@ -102,3 +102,28 @@ def test_fuzz_draws_in_split3_mode(lib_built, seed):
     tol_f = max(1e-4 * max(1.0, np.abs(F64).max()), 4 * np.abs(F32 - F64).max())
     assert (np.abs(e - E64) <= tol_e).all(), (hp, sizes, np.abs(e - E64).max())
     assert np.abs(f - F64).max() <= tol_f, (hp, sizes, np.abs(f - F64).max(), tol_f)
+
+
+@pytest.mark.parametrize("fuse_panel", [1, 0])
+def test_fragment_batch_in_split3_mode(lib_built, fuse_panel):
+    """Batch regime (N >= 4096: one wave per node, 128 x 128 product tiles): in the mode the PLAIN products run the
+    128 x 128 split tile (k_gemm3_128); the fused panel products (fuse_panel = 1) keep their fp32 MFMA prologue
+    kernels.  Replica 0 of a tiled batch against the fp64 oracle, every replica bit-identical to it."""
+    hp = default_hparams(embedding_dimension=256, num_layers=3)
+    z1, p1, s1, e1 = random_fragments(6, [27, 12, 33])
+    reps, n1 = 80, 72
+    z = np.tile(z1, reps)
+    pos = np.tile(p1, (reps, 1))
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    assert len(z1) == n1 and len(z) >= 4096
+    m = split3(model_for(hp, 4))
+    m.engine.set_option("fuse_panel", fuse_panel)
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    E64, F64, _ = ViSNetOracle(hp, make_state_dict(hp, seed=4), torch.float64).energy_forces(z1, p1, s1, e1)
+    check(e.reshape(reps, -1)[0].reshape(-1, 1), f.reshape(reps, n1, 3)[0], E64, F64)
+    assert np.array_equal(f.reshape(reps, n1, 3), np.broadcast_to(f.reshape(reps, n1, 3)[0], (reps, n1, 3)))
+    m.engine.set_option("gemm_split3", 0)
+    e0, f0 = m.dl_potential_loader(frag(z, pos, start, end))
+    assert not np.array_equal(f0, f)  # the mode really took the other kernel
+    np.testing.assert_allclose(f, f0, rtol=0, atol=2e-5)

@@ -52,6 +52,21 @@ for wl, (tag, pats) in want.items():
             if pat in r["kernel"] and r.get("hbm_MB") not in (None, "", "nan"):
                 res.setdefault(wl, {})[key] = float(r["hbm_MB"]) * 1e6
                 break
+# avg / min duration of the same kernels in the kernel trace of the same command (bench.py lays its live
+# dispatch-timestamp figures beside them: roofline.hbm.rocprof); all instantiations of a name pooled by calls
+kn = {}
+for wl, (tag, pats) in want.items():
+    rows = list(csv.DictReader(open(f"{out}/{tag}_kernel_stats.csv")))
+    for pat, key in pats:
+        pat = pat.replace("; ", ", ").rstrip("<")
+        hit = [r for r in rows if pat.split("<")[0] in r["kernel"] and (key != "k_node_update" or "k_node_update" in r["kernel"])]
+        if key in ("k_gemm<128,128>",):
+            hit = [r for r in rows if "k_gemmILi128ELi128E" in r["kernel"]]
+        if hit:
+            calls = sum(int(r["calls"]) for r in hit)
+            kn.setdefault(wl, {})[key] = dict(calls=calls, avg_ns=sum(int(r["total_ns"]) for r in hit) / calls,
+                                              min_ns=min(int(r["min_ns"]) for r in hit))
+res["kernel_ns"] = kn
 res["build_digest"] = _digest()
 res["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KB*1024) averaged over all launches of the kernel in "
                 "the <tag>_pmc.csv of this directory (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, "
