@@ -124,6 +124,7 @@ struct vsn_ctx {
   bool split_rev = true;  // K-slices of the g_m / g_A products summed by their consumer (single-protein sizes)
   bool fuse_panel = true;  // fragment batches, hidden 256: gather kernels as prologues of panel GEMMs (fused.hip)
   int64_t panel_min_edges = (int64_t)1 << 40;  // ... and below the batch regime from this many edge slots on (A/B aid: off)
+  bool reduce_mean = false;   // hparams reduce_op == "mean" (visnet.py:146): per-fragment mean instead of sum
   bool gemm_split3 = false;   // opt-in: grouped products as 3 x bf16 split MFMA products (gemm_s3.h); default fp32 MFMA
   Split3Table* s3 = nullptr;  // ... and the packed bf16 planes of this engine's weights (made on first use)
   // debug snapshots: name -> per-layer device copies
@@ -243,6 +244,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->fuse_panel = value != 0;
   } else if (k == "panel_min_edges") {
     c->panel_min_edges = value;
+  } else if (k == "reduce_mean") {
+    c->reduce_mean = value != 0;
   } else if (k == "gemm_split3") {
     // opt-in arithmetic mode (default 0 = fp32 MFMA everywhere): the grouped products of single-protein sizes as
     // 3 x bf16 split products with fp32 accumulation (gemm_s3.h).  Plain launches (batches, read-out) stay fp32.
@@ -1118,6 +1121,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     if (head_defers_energy(D, c->hw)) ef = EnergyFold{Bn, c->fstart, c->fend, c->hb.y, c->hw.mean, e_out};
     RC(launch_bwd_geom(st, g, c->g_rbf, c->g_geo, c->g_ev, f_out, c->debug, ef));
   }
+  if (c->reduce_mean) RC(launch_reduce_mean(st, Bn, c->fstart, c->fend, c->hw.mean, e_out, f_out));
 #undef RC
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(c, -5, std::string("kernel launch error: ") + hipGetErrorString(le));

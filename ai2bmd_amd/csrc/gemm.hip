@@ -342,9 +342,28 @@ __global__ __launch_bounds__(256) void k_gemm_group(GemmGroup g) {
       p = q + 1;
     }
   const GemmDesc& d = g.p[p];
-  if (d.flags & VSN_S3_FLAG)  // opt-in mode gemm_split3: this member's weight operand is its packed bf16 planes
-    gemm_body3(d.A, d.lda, reinterpret_cast<const unsigned short*>(d.Bt), d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc,
-               d.K, d.flags, d.ksplit, d.part, b, smem);
+  gemm_body<64, 64, 2, 2, true, 0, 32>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
+                                           d.flags, d.ksplit, d.part, b, smem);
+}
+// the grouped launch of the opt-in mode gemm_split3: members marked VSN_S3_FLAG carry packed bf16 planes as their
+// weight operand and run the split tile, the others the fp32 tile.  A kernel of its own, so that the
+// default fp32 launch above is the same binary whether or not the mode exists.
+#ifndef VSN_S3_MINWAVES
+#define VSN_S3_MINWAVES 4  // waves per SIMD asked of the compiler (A/B builds: tools/build_variant.py -DVSN_S3_MINWAVES=5)
+#endif
+__global__ __launch_bounds__(256, VSN_S3_MINWAVES) void k_gemm_group_s3(GemmGroup g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // 24 KiB (split tiles only) or 32 KiB (an fp32 member)
+  int b = (int)blockIdx.x, p = 0;
+#pragma unroll
+  for (int q = 0; q < GemmGroup::MAXP - 1; ++q)
+    if (p == q && q + 1 < g.n && b >= g.p[q].blocks) {
+      b -= g.p[q].blocks;
+      p = q + 1;
+    }
+  const GemmDesc& d = g.p[p];
+  if (d.flags & VSN_S3_FLAG)
+    gemm_body3(d.A, d.lda, reinterpret_cast<const unsigned short*>(d.Bt), d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr,
+               d.Nc, d.K, d.flags, d.ksplit, d.part, b, smem);
   else
     gemm_body<64, 64, 2, 2, true, 0, 32>(d.A, d.lda, d.Bt, d.ldb, d.C, d.ldc, d.bias, d.M, d.Mptr, d.Nc, d.K,
                                          d.flags, d.ksplit, d.part, b, smem);
@@ -591,10 +610,14 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
   size_t ws_off = 0;
   GemmDesc red[GemmGroup::MAXP];
   int nred = 0;
+  bool any_s3 = false;
+  unsigned lds_s3 = 24576;
   for (int i = 0; i < n; ++i) {
     GemmDesc d = descs[i];
     if (d.M <= 0) continue;
-    s3_patch(d, st);
+    s3_patch(d, st);  // (opt-in mode gemm_split3)
+    any_s3 |= (d.flags & VSN_S3_FLAG) != 0;
+    if (!(d.flags & VSN_S3_FLAG)) lds_s3 = 32768;  // an fp32 member in the split launch: its tile needs 32 KiB
     const int t = ((d.M + 63) / 64) * (d.Nc / 64);
     int ks = 1;
     if (d.keep_parts > 1) {
@@ -628,7 +651,8 @@ int launch_gemm_group(hipStream_t st, const GemmDesc* descs, int n) {
     g.p[g.n++] = d;
   }
   if (g.n > 0) {
-    hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
+    if (any_s3) hipLaunchKernelGGL(k_gemm_group_s3, dim3(grid), dim3(256), lds_s3, st, g);
+    else hipLaunchKernelGGL(k_gemm_group, dim3(grid), dim3(256), 0, st, g);
   }
   if (nred == 1) {
     const GemmDesc& d = red[0];

@@ -13,6 +13,10 @@
 // one k-tile ahead.  The ACTIVATIONS are split on their way into LDS, which holds the three A planes only (two
 // stages of 12 KiB, one barrier per k-tile).
 //
+// Measured and left out (round 4, LAB_NOTES section 11): 128-row tiles in the grouped launch (a wave owning two MFMA
+// tiles that share its B fragment: a third fewer bytes through the L1 per product, but 146 registers = three waves per
+// SIMD and half the tiles - Chignolin 488 -> 469 steps/s with every member tall, 490 with the E-row members only).
+//
 // (spliced into gemm.hip INSIDE namespace vsn, after gemm_body)
 #pragma once
 

@@ -481,6 +481,27 @@ int launch_graph(hipStream_t st, const GraphArgs& a) {
   return 0;
 }
 
+// reduce_op = "mean" (ViSNet/model/visnet.py:146: scatter(x, batch, reduce="mean")): the per-fragment energy is the
+// MEAN of the atomic terms, E_b = (sum_i y_i) / n_b + mean.  Fragments are independent, so against the "add" evaluation
+// this is a per-fragment scale of the energy sum and of the forces of the fragment's atoms - one wave per fragment.
+__global__ __launch_bounds__(256) void k_reduce_mean(int B, const int* __restrict__ fstart,
+                                                     const int* __restrict__ fend, float mean,
+                                                     float* __restrict__ e_out, float* __restrict__ f_out) {
+  const int b = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), l = threadIdx.x & 63;
+  if (b >= B) return;
+  const int a0 = fstart[b], a1 = fend[b];
+  if (a1 <= a0) return;  // (an empty fragment keeps `mean`, as in the "add" evaluation)
+  const float inv = 1.0f / (float)(a1 - a0);
+  if (l == 0) e_out[b] = (e_out[b] - mean) * inv + mean;
+  for (int k = 3 * a0 + l; k < 3 * a1; k += 64) f_out[k] *= inv;
+}
+int launch_reduce_mean(hipStream_t st, int B, const int* fstart, const int* fend, float mean, float* e_out,
+                       float* f_out) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(k_reduce_mean, dim3((B + 3) / 4), dim3(256), 0, st, B, fstart, fend, mean, e_out, f_out);
+  return 0;
+}
+
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
                     float* f_out, bool keep_g_ev, const EnergyFold& ef) {
   if (a.N <= 0) return ef.B > 0 ? -22 : 0;

@@ -143,6 +143,10 @@ struct EnergyFold {
 int launch_bwd_geom(hipStream_t st, const GraphArgs& a, const float* g_rbf, const float* g_geo, float* g_ev,
                     float* f_out, bool keep_g_ev, const EnergyFold& ef);
 
+// reduce_op = "mean": per-fragment scale of the finished "add" evaluation (energies and forces), graph.hip
+int launch_reduce_mean(hipStream_t st, int B, const int* fstart, const int* fend, float mean, float* e_out,
+                       float* f_out);
+
 // ---- forward ----
 int launch_embed_node(hipStream_t st, const Dims& D, const float* emb1, const float* emb2, const float* pp,
                       float* cat);

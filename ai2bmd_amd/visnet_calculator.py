@@ -43,7 +43,7 @@ class ViSNetEngine:
         self._L = L
         for key, ok in (("rbf_type", tuple(capi.RBF)), ("activation", tuple(capi.ACTIVATION)),
                         ("attn_activation", tuple(capi.ACTIVATION)), ("model", ("ViSNetBlock",)),
-                        ("output_model", ("Scalar",)), ("reduce_op", ("add",))):
+                        ("output_model", ("Scalar",)), ("reduce_op", ("add", "mean"))):
             if hparams.get(key, ok[0]) not in ok:
                 raise NotImplementedError(f"{key}={hparams.get(key)!r} is not built in the HIP path (supported: {ok})")
         prior = hparams.get("prior_model")
@@ -80,6 +80,8 @@ class ViSNetEngine:
             self._check(rc)
         torch.cuda.synchronize(self.device)
         self._check(L.vsn_finalize(self._h))
+        if hparams.get("reduce_op", "add") == "mean":  # visnet.py:146: per-fragment mean of the atomic terms
+            self.set_option("reduce_mean", 1)
 
     def _check(self, rc):
         if rc != 0:

@@ -855,6 +855,18 @@ def main():
                                        "fp32 MFMA utilisation")
             r_3["keep_parity"] = True
             secondary.append(r_3)
+            # the same mode on the fragment batch (plain products on the 128 x 128 split tile; the fused panel
+            # products keep their fp32 MFMA kernels)
+            eng.set_option("gemm_split3", 1)
+            try:
+                r_b3 = run_frag_batch(ctx, eng, hp, args, 6, 1)
+            finally:
+                eng.set_option("gemm_split3", 0)
+            r_b3["metric"] += " (opt-in mode gemm_split3)"
+            r_b3["dtype"] = r_3["dtype"]
+            r_b3["roofline"]["note"] = r_3["roofline"]["note"]
+            r_b3["keep_parity"] = True
+            secondary.append(r_b3)
     out = dict(
         metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=ctx.world, steps=res["steps"],
         steps_requested=args.steps_requested, warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True,

@@ -49,6 +49,8 @@ CASES = {
     "h384_l2_lmax1": (dict(embedding_dimension=384, num_layers=2, lmax=1), 25, 115, [30, 12]),
     "h448_l2": (dict(embedding_dimension=448, num_layers=2, num_heads=4), 26, 116, [19, 12]),
     "h512_l3": (dict(embedding_dimension=512, num_layers=3), 27, 117, [22, 12, 33]),
+    # reduce_op = "mean" (visnet.py:146): per-fragment mean of the atomic terms; an empty fragment in the batch
+    "h64_l2_mean": (dict(embedding_dimension=64, num_layers=2, reduce_op="mean"), 28, 118, [22, 0, 12, 31]),
 }
 
 

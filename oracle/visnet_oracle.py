@@ -359,7 +359,10 @@ class ViSNetOracle:
         batch = np.zeros(N, np.int64)
         for bi, fi in enumerate(valid):
             batch[start[fi]:end[fi]] = bi
-        Eb = torch.zeros(len(valid), 1, dtype=dt).index_add(0, torch.from_numpy(batch), y) + self.w["mean"]
+        Eb = torch.zeros(len(valid), 1, dtype=dt).index_add(0, torch.from_numpy(batch), y)
+        if self.hp.get("reduce_op", "add") == "mean":  # visnet.py:146 scatter(..., reduce=self.reduce_op)
+            Eb = Eb / torch.as_tensor((end - start)[valid], dtype=dt)[:, None]
+        Eb = Eb + self.w["mean"]
         c["graph"] = graph
         c["z"] = z
         return Eb[:, 0], c
@@ -391,6 +394,9 @@ class ViSNetOracle:
 
         # ---- read-out ----
         g_h1 = w["std"] * w[on + "1.update_net.2.weight"][0][None, :].expand(N, h2)
+        if self.hp.get("reduce_op", "add") == "mean":  # dE_b / dy_i = 1 / n_b
+            st_, en_ = np.asarray(start), np.asarray(end)
+            g_h1 = g_h1 / torch.as_tensor(np.repeat((en_ - st_), (en_ - st_)), dtype=dt)[:, None]
         g_a1 = g_h1 * self.dact(c["a1b"])
         g_cat1 = g_a1 @ w[on + "1.update_net.0.weight"]  # [N,H]
         g_x1, g_v1b = g_cat1[:, :h2], g_cat1[:, h2:]
