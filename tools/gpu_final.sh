@@ -1,0 +1,27 @@
+#!/bin/bash
+# End-of-round evidence on one box: the -m gpu suite, the round's profiles (kernel traces + PMC passes + traffic json),
+# then the default bench line with the traffic json of THIS build in place.   usage: bash tools/gpu_final.sh r04
+set -u
+R=$PWD
+TAG=${1:-round}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1
+echo "pytest rc=$?" >> "$OUT/pytest.log"
+tail -n 3 "$OUT/pytest.log"
+bash tools/profile_round.sh "$TAG" > "$OUT/profile_round.log" 2>&1
+cd "$R"
+cp "$OUT/pmc_traffic.json" "profiles/${TAG}_pmc_traffic.json"
+timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
+echo "bench rc=$?"
+python - "$OUT/bench_line.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("value", d["value"], "steps", d["steps"], d["config"].get("requested_run", {}).get("value"))
+r = d["roofline"]; print("gemm", r["kernel"], round(r["frac"], 4), round(r["avg_launch_us"], 2), "traffic", r["traffic"])
+h = r["hbm"]; print("hbm", h["kernel"], round(h["frac"], 4), round(h["avg_launch_us"], 2), "traffic", h["traffic"], h.get("rocprof"))
+c = d["cpu_baseline"]; print("cpu", {k: c[k] for k in ("value", "cores", "kind", "physical_cores", "layout_of_value", "reference_layout_evals_per_s")})
+for k, v in d["config"].get("secondary_summary", {}).items():
+    print("  ", k, round(v["value"], 1), v["unit"], v["steps"])
+PY
+ls "$OUT"
