@@ -194,3 +194,31 @@ def test_hparams_of_module_reads_scripted_activation_names():
     assert _act_name(Scripted()) == "ssp" and _act_name(torch.nn.SiLU()) == "silu" and _act_name(torch.nn.Tanh()) == "tanh"
     with pytest.raises(TypeError):
         _act_name(torch.nn.ReLU())
+
+
+def test_bench_cpu_baseline_helpers():
+    """bench.py's CPU-baseline plumbing without a GPU: the physical core count is read like the reference reads it
+    (utils/system.py:28-45: lscpu, sockets x cores per socket), the median protocol keeps >= 3 timed evaluations, and
+    the evaluator it times is the REFERENCE's model (kind "reference": the source tree here, oracle/_ref on the GPU
+    box) whenever either is present."""
+    import subprocess
+
+    import bench
+    from oracle.ref_import import reference_model_source
+    from oracle.weights import default_hparams, make_state_dict
+
+    n = bench.physical_core_count()
+    out = subprocess.run(["lscpu"], capture_output=True, text=True).stdout
+    if "Core(s) per socket:" in out:
+        assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
+    calls = []
+    rate, k = bench._median_rate(lambda: calls.append(1), warm=2, timed=5)
+    assert k == 5 and len(calls) == 7 and rate > 0
+    hp = default_hparams(embedding_dimension=64, num_layers=1)
+    kind, origin, fn = bench._cpu_evaluator(hp, make_state_dict(hp, seed=1))
+    assert (kind == "reference") == (reference_model_source() is not None)
+    from oracle.inputs import random_fragments
+
+    z, pos, start, end = random_fragments(1, [12, 19])
+    E, F = fn(z, pos, start, end)
+    assert np.asarray(E).reshape(-1).shape == (2,) and np.asarray(F).shape == (len(z), 3)
