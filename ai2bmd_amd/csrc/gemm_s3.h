@@ -324,10 +324,10 @@ static const unsigned short* s3_planes(const float* Bt, int ldb, int Nc, int K, 
     unsigned short* p = nullptr;
     if (hipMalloc((void**)&p, 3 * (size_t)Nc * ldb * sizeof(unsigned short)) != hipSuccess) return nullptr;
     hipLaunchKernelGGL(k_s3_pack, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, Bt, elems, ldb, p);
-    if (it != tl_s3->cache.end()) {
-      hipStreamSynchronize(st);  // (a smaller view of the same operand was cached: its users are done before it goes)
-      hipFree(it->second.planes);
-    }
+    // once per weight matrix: the planes are complete before anybody - a later call on ANOTHER stream included - can
+    // read them (and a smaller cached view of the same operand has no users left when it is freed)
+    hipStreamSynchronize(st);
+    if (it != tl_s3->cache.end()) hipFree(it->second.planes);
     tl_s3->cache[Bt] = Split3Table::Entry{p, elems};
     it = tl_s3->cache.find(Bt);
   }

@@ -222,3 +222,45 @@ def test_bench_cpu_baseline_helpers():
     z, pos, start, end = random_fragments(1, [12, 19])
     E, F = fn(z, pos, start, end)
     assert np.asarray(E).reshape(-1).shape == (2,) and np.asarray(F).shape == (len(z), 3)
+
+
+def test_bench_step_policy_and_defaults():
+    """bench.py argument policy: chig_md is BASELINE configs[1] = the 1000-step loop (default steps 1000; a smaller
+    --steps is remembered as steps_requested and timed first by run_md), the other workloads time exactly what was
+    asked; --min-seconds is off unless asked for."""
+    import bench
+
+    a = bench.parse_args([])
+    assert a.workload == "chig_md" and a.steps == bench.C2_STEPS == 1000 and a.steps_requested is None
+    assert a.min_seconds == 0.0 and a.gpus == 1
+    a = bench.parse_args(["--steps", "20", "--warmup", "5"])
+    assert a.steps == 20 and a.steps_requested == 20 and a.warmup == 5
+    assert bench.parse_args(["--workload", "frag_batch"]).steps == 2
+    assert bench.parse_args(["--workload", "trpcage_md"]).steps == 200
+
+
+def test_compiled_reference_is_refused_for_another_interpreter(tmp_path, monkeypatch):
+    """oracle/_ref is bytecode: a manifest written by another interpreter version (different magic) is not used"""
+    import json
+
+    from oracle import ref_import
+
+    d = tmp_path / "_ref"
+    (d / "ViSNet" / "model").mkdir(parents=True)
+    (d / "ViSNet" / "model" / "visnet.pyc").write_bytes(b"x")
+    (d / "MANIFEST.json").write_text(json.dumps(dict(magic="00000000", python="0.0", modules={})))
+    monkeypatch.setattr(ref_import, "COMPILED_REF", str(d))
+    assert not ref_import.compiled_reference_available()
+    import importlib.util
+
+    (d / "MANIFEST.json").write_text(json.dumps(dict(magic=importlib.util.MAGIC_NUMBER.hex(), python="x", modules={})))
+    assert ref_import.compiled_reference_available()
+
+
+def test_preprocessed_order_rejects_unknown_atoms():
+    from ai2bmd_amd.fragmentation import ProteinAtoms, preprocessed_order
+
+    p = ProteinAtoms(np.array(["CH3", "C", "O", "H1", "H2", "HX"]), np.array(["ACE"] * 6), np.array([1] * 6),
+                     np.array([6, 6, 8, 1, 1, 1]), np.zeros((6, 3)))
+    with pytest.raises(ValueError):
+        preprocessed_order(p)
