@@ -168,21 +168,34 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   constexpr bool PREC = (MI * NI == 1);  // one-accumulator tile (64x64, the grouped reverse-pass products)
   const bool accum = (flags & 1) != 0;
   const bool acc_out = accum && ksplit == 1;
-  float bvs[NI];  // bias: fetched now - at the end of the tile it would be a full round trip on the tail
+  // MFMA operand roles are SWAPPED (weights as its "A", activations as its "B": D[n][m] = sum_k W[n][k] X[m][k]), so a
+  // lane ends up with ONE output row (m = l31) and 16 output columns in four runs of four consecutive ones
+  // (col = 8 q + 4 hi + 0..3): the epilogue is 4 x 16-byte stores per accumulator instead of 16 x 4-byte ones (and the
+  // accumulate-from-C prologue 4 x 16-byte loads).  Same products in the same k order: bitwise the same sums.
+  // bias: the one-accumulator tile (K = 256: eight k-iterations, the tail matters) fetches its sixteen values now -
+  // at the end of the tile they would be a full round trip on the tail; the 128-wide tiles would pay 32 registers
+  // across the k-loop for that (a wave per SIMD less) and fetch them in the epilogue instead
+  constexpr bool BIAS_EARLY = (MI * NI == 1);
+  const bool has_bias = bias && ksplit == 1;
+  f32x4 bvs[BIAS_EARLY ? 4 : 1];
+  if (BIAS_EARLY) {
 #pragma unroll
-  for (int j = 0; j < NI; ++j) bvs[j] = (bias && ksplit == 1) ? bias[col0 + wn * TN + j * 32 + l31] : 0.f;
+    for (int q = 0; q < 4; ++q)
+      bvs[q] = has_bias ? *reinterpret_cast<const f32x4*>(bias + col0 + wn * TN + 8 * q + 4 * hi)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   f32x16 acc[MI][NI];
   if (PREC && acc_out) {
     // accumulate mode: the accumulator STARTS from the old C values (no second pass over C in the epilogue, and
     // no sixteen registers holding them across the k-loop)
     const float* cp = C + (size_t)row0 * ldc + col0;
-    const int rlim = Meff - row0 - (wm * TM + 4 * hi);
-    const unsigned off = (unsigned)(wm * TM + 4 * hi) * (unsigned)ldc + (unsigned)(wn * TN + l31);
+    const bool row_ok = row0 + wm * TM + l31 < Meff;
+    const unsigned off = (unsigned)(wm * TM + l31) * (unsigned)ldc + (unsigned)(wn * TN + 4 * hi);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int dr = (r & 3) + 8 * (r >> 2);
-      acc[0][0][r] = dr < rlim ? cp[off + (unsigned)dr * (unsigned)ldc] : 0.f;
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 o_ = row_ok ? *reinterpret_cast<const f32x4*>(cp + off + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[0][0][4 * q] = o_.x, acc[0][0][4 * q + 1] = o_.y, acc[0][0][4 * q + 2] = o_.z, acc[0][0][4 * q + 3] = o_.w;
     }
   } else {
 #pragma unroll
@@ -234,10 +247,10 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].x, fb[cur][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].y, fb[cur][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].z, fb[cur][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i].w, fb[cur][j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j].x, fa[cur][i].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j].y, fa[cur][i].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j].z, fa[cur][i].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[cur][j].w, fa[cur][i].w, acc[i][j], 0, 0, 0);
         }
       if (DB && kk == KK / 2 - 1) {
         // Half-way through the MFMA block: tile kt+1 (in registers since the last iteration) goes to the other
@@ -282,30 +295,25 @@ __device__ __forceinline__ void gemm_body(const float* __restrict__ A, int lda, 
   // predicates on a tile that lies wholly below Meff.
   float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
   const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
-  const bool full = row0 + BM <= Meff;
   const bool rmw = acc_out && !PREC;  // multi-accumulator tiles add the old C here
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+  for (int i = 0; i < MI; ++i) {
+    const bool row_ok = row0 + wm * TM + i * 32 + l31 < Meff;  // this lane's output row
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const unsigned off = (unsigned)(wm * TM + i * 32 + 4 * hi) * ldo + (unsigned)(wn * TN + j * 32 + l31);
-      const float bv = bvs[j];  // 0 when split-K
-      if (full && !rmw) {
+      float* cp = Ct + ((unsigned)(wm * TM + i * 32 + l31) * ldo + (unsigned)(wn * TN + j * 32 + 4 * hi));
+      if (row_ok) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Ct[off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo] = acc[i][j][r] + bv;
-      } else {
-        const int rlim = full ? BM : Meff - row0 - (wm * TM + i * 32 + 4 * hi);  // rows of this strip below Meff
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if ((r & 3) + 8 * (r >> 2) < rlim) {
-            float* cp = Ct + (off + (unsigned)((r & 3) + 8 * (r >> 2)) * ldo);
-            float v = acc[i][j][r] + bv;
-            if (rmw) v += *cp;
-            *cp = v;
-          }
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if (BIAS_EARLY) v += bvs[q];
+          else if (has_bias) v += *reinterpret_cast<const f32x4*>(bias + col0 + wn * TN + j * 32 + 8 * q + 4 * hi);
+          if (rmw) v += *reinterpret_cast<const f32x4*>(cp + 8 * q);
+          *reinterpret_cast<f32x4*>(cp + 8 * q) = v;
         }
       }
     }
+  }
   VSN_STAMP_AT(63);  // epilogue stores issued
 #undef VSN_GLOAD
 #undef VSN_SSTORE
@@ -447,7 +455,7 @@ int gemm_variant(int M, int Nc) {
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags) {
   if (M <= 0) return 0;
-  if ((K & 31) || (Nc & 31) || (lda & 3) || (ldb & 3)) return -22;
+  if ((K & 31) || (Nc & 31) || (lda & 3) || (ldb & 3) || (ldc & 3)) return -22;  // (16-byte row pieces everywhere)
   GemmProfiler::Rec* rec = nullptr;
   if (tl_prof) {
     tl_prof->recs.emplace_back();
