@@ -40,9 +40,10 @@ class DipeptideBondedCombiner:
     @staticmethod
     def forces_combine(prot_len, dipeptides_forces, ACE_NMEs_forces, select_index, origin_index):
         cat = np.concatenate([np.asarray(dipeptides_forces), -np.asarray(ACE_NMEs_forces)])[np.asarray(select_index)]
-        out = np.zeros((prot_len, 3), dtype=np.float32)
-        np.add.at(out, np.asarray(origin_index), cat)
-        return out
+        oi = np.asarray(origin_index)
+        # scatter_sum(cat, origin_index) (combiner.py:38-39) as three bincounts: rows are added in index order like
+        # np.add.at, in float64 (np.add.at is an order of magnitude slower per call and this runs every MD step)
+        return np.stack([np.bincount(oi, weights=cat[:, k], minlength=prot_len) for k in range(3)], 1).astype(np.float32)
 
 
 class DLBondedCalculator:
@@ -95,14 +96,23 @@ class DLBondedCalculator:
         for dev, f0, f1 in work:
             if f1 > f0:
                 parts[dev].append(fragments[f0:f1])
-        with ThreadPoolExecutor(len(self.models)) as ex:
-            futs = [ex.submit(self._inference_impl, d, m) for d, m in zip(parts, self.models)]
+        if len(self.models) == 1:  # one device: no hand-off to a worker thread (bonded.py:75-77 starts one per device)
+            res = [self._inference_impl(parts[0], self.models[0])]
+        else:
+            if getattr(self, "_pool", None) is None:
+                self._pool = ThreadPoolExecutor(len(self.models))  # kept: a pool per call costs ~0.1 ms of every step
+            futs = [self._pool.submit(self._inference_impl, d, m) for d, m in zip(parts, self.models)]
             res = [f.result() for f in futs]
-        energy = np.concatenate([e for r in res for e in r[0]])
-        forces = np.concatenate([f for r in res for f in r[1]])
-        e_dip, e_ace = (energy[s] for s in fragments.scalar_split())
-        f_dip, f_ace = (forces[s] for s in fragments.vector_split())
-        return e_dip, f_dip, e_ace, f_ace
+        es = [e for r in res for e in r[0]]
+        fs = [f for r in res for f in r[1]]
+        energy = es[0] if len(es) == 1 else np.concatenate(es)
+        forces = fs[0] if len(fs) == 1 else np.concatenate(fs)
+        # the dipeptide / ACE-NME masks depend on the fragment offsets only, which are fixed for a simulation
+        key = (id(fragments.start), id(fragments.end), len(fragments))
+        if getattr(self, "_split_key", None) != key:
+            self._split_key, self._splits = key, (fragments.scalar_split(), fragments.vector_split())
+        (sd, sa), (vd, va) = self._splits
+        return energy[sd], forces[vd], energy[sa], forces[va]
 
     def __call__(self, prot):
         """-> (energy, forces[n_prot,3]) like bonded.py:102-123: fragments of the current positions (cap hydrogens
