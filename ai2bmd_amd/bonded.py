@@ -108,7 +108,7 @@ class DLBondedCalculator:
         energy = es[0] if len(es) == 1 else np.concatenate(es)
         forces = fs[0] if len(fs) == 1 else np.concatenate(fs)
         # the dipeptide / ACE-NME masks depend on the fragment offsets only, which are fixed for a simulation
-        key = (id(fragments.start), id(fragments.end), len(fragments))
+        key = (np.asarray(fragments.start).tobytes(), np.asarray(fragments.end).tobytes())  # (content, not identity)
         if getattr(self, "_split_key", None) != key:
             self._split_key, self._splits = key, (fragments.scalar_split(), fragments.vector_split())
         (sd, sa), (vd, va) = self._splits
