@@ -121,6 +121,28 @@ __device__ __forceinline__ float wave_multi_sum(const float (&p)[P], int lane) {
   return v;
 }
 
+// Per-head sums for ANY head count: lane l owns channels l V .. l V + V - 1, head(c) = c / hd.  out[t] = the sum of val
+// over all channels of the head of the lane's channel t.  One wave reduction per head (the power-of-two fast path is
+// group_sum over 64 / nh lanes); fixed order.
+template <int V>
+__device__ __forceinline__ void head_sums_any(const float (&val)[V], int lane, int hd, int nh, float (&out)[V]) {
+  int hidx[V];
+#pragma unroll
+  for (int t = 0; t < V; ++t) {
+    hidx[t] = (lane * V + t) / hd;
+    out[t] = 0.f;
+  }
+  for (int h = 0; h < nh; ++h) {
+    float p = 0.f;
+#pragma unroll
+    for (int t = 0; t < V; ++t) p += hidx[t] == h ? val[t] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+#pragma unroll
+    for (int t = 0; t < V; ++t) out[t] = hidx[t] == h ? p : out[t];
+  }
+}
+
 // sum over aligned groups of `width` consecutive lanes (width power of two)
 __device__ __forceinline__ float group_sum(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

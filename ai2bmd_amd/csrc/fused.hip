@@ -257,7 +257,9 @@ static const bool g_fused_env = [] {
   return true;
 }();
 
-bool panel_ok(const Dims& D) { return g_fuse_panel && D.H == 256 && D.S == 8 && D.nh >= 2 && D.nh <= 64; }
+bool panel_ok(const Dims& D) {  // (head counts that divide 64: the fused prologues sum heads over lane groups)
+  return g_fuse_panel && D.H == 256 && D.S == 8 && D.nh >= 2 && D.nh <= 64 && !D.hgen;
+}
 
 // the attribute is per DEVICE: remembered per (current device, kernel), so a thread that drives engines on several
 // GPUs sets it on each of them

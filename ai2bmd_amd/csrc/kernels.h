@@ -44,6 +44,10 @@ struct GraphArgs {
 struct Dims {
   int N, Emax, H, S, nh, R, Rp;
   int act, attn_act;  // VSN_ACT_* of hparams "activation" / "attn_activation" (common.h)
+  // heads: hd = H / nh channels per head.  hgen = 0: nh divides 64 (a head = 64 / nh whole lanes: group_sum fast path);
+  // hgen = 1: any other nh with H % nh == 0 (visnet_block.py:158-166 asks no more) - a lane's channels may straddle
+  // heads; the kernels that form per-head sums take their generic instantiation (head_sums_any, common.h)
+  int hd, hgen;
   const int* ecount;
   const int* rowptr;
   const int* colptr;

@@ -551,25 +551,57 @@ __device__ __forceinline__ void bwd_attn_T_body(const Dims& D, const float* __re
         gpart += gm[c] * v[c] * dv[c];
       }
       strow<V>(g_m + (size_t)e * H, lane, gm);
-      const float sat = group_sum(part, lph);
-      const float ga = group_sum(gpart, lph);
-      float ssat, dssat;
-      act_both((GEN ? D.attn_act : VSN_ACT_SILU), sat, ssat, dssat);
-      const float a = ssat * C;
-      const float gsat = ga * dssat * C;
-      const bool head_lead = (lane & (lph - 1)) == 0;
-      const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
-      if (lane == 0) g_geo[(size_t)e * VSN_GEO_W + 8] = gC_old + gC;
-      if (head_lead) {
-        sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
-        sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
+      float av[V], gsv[V];  // a and g_sat of the head of each of the lane's channels
+      bool any_heads = false;
+      if constexpr (GEN) any_heads = D.hgen != 0;
+      if (any_heads) {  // head count that does not divide 64 (see head_sums_any)
+        float pc[V], gc[V], sc[V], gac[V];
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          pc[c] = q[c] * k[c] * dk[c];
+          gc[c] = gm[c] * v[c] * dv[c];
+        }
+        head_sums_any<V>(pc, lane, D.hd, nh, sc);
+        head_sums_any<V>(gc, lane, D.hd, nh, gac);
+        float gcp = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) {
+          float ssat, dssat;
+          act_both(D.attn_act, sc[c], ssat, dssat);
+          av[c] = ssat * C;
+          gsv[c] = gac[c] * dssat * C;
+          const int ch = lane * V + c;
+          if (ch % D.hd == 0) {  // the first channel of a head writes the head's pair and carries its dE/dC term
+            gcp += gac[c] * ssat;
+            sat_tmp[(size_t)e * 2 * nh + ch / D.hd] = gsv[c];
+            sat_tmp[(size_t)e * 2 * nh + nh + ch / D.hd] = av[c];
+          }
+        }
+        const float gC = wave_sum(gcp);
+        if (lane == 0) g_geo[(size_t)e * VSN_GEO_W + 8] = gC_old + gC;
+      } else {
+        const float sat = group_sum(part, lph);
+        const float ga = group_sum(gpart, lph);
+        float ssat, dssat;
+        act_both((GEN ? D.attn_act : VSN_ACT_SILU), sat, ssat, dssat);
+        const float a = ssat * C;
+        const float gsat = ga * dssat * C;
+        const bool head_lead = (lane & (lph - 1)) == 0;
+        const float gC = wave_sum(head_lead ? ga * ssat : 0.f);
+        if (lane == 0) g_geo[(size_t)e * VSN_GEO_W + 8] = gC_old + gC;
+        if (head_lead) {
+          sat_tmp[(size_t)e * 2 * nh + lane / lph] = gsat;
+          sat_tmp[(size_t)e * 2 * nh + nh + lane / lph] = a;
+        }
+#pragma unroll
+        for (int c = 0; c < V; ++c) av[c] = a, gsv[c] = gsat;
       }
       float gpk[V], gpv[V];
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        gpk[c] = gsat * q[c] * k[c] * ddk[c];
-        gpv[c] = gm[c] * v[c] * a * ddv[c];
-        gq[0][c] += gsat * k[c] * dk[c];
+        gpk[c] = gsv[c] * q[c] * k[c] * ddk[c];
+        gpv[c] = gm[c] * v[c] * av[c] * ddv[c];
+        gq[0][c] += gsv[c] * k[c] * dk[c];
       }
       strow<V>(g_pe + (size_t)e * 3 * H, lane, gpk);
       strow<V>(g_pe + (size_t)e * 3 * H + H, lane, gpv);
@@ -659,12 +691,19 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
       ldrow<V>(g_m + (size_t)e * H, lane, gm);
-      const float gsat = sat_tmp[(size_t)e * 2 * nh + lane / lph];
-      const float a = sat_tmp[(size_t)e * 2 * nh + nh + lane / lph];
+      float gsv[V], av[V];
+      bool any_heads = false;
+      if constexpr (GEN) any_heads = D.hgen != 0;
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        g2[0][c] += gsat * q[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
-        g2[1][c] += gm[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * a;
+        const int h = any_heads ? (lane * V + c) / D.hd : lane / lph;
+        gsv[c] = sat_tmp[(size_t)e * 2 * nh + h];
+        av[c] = sat_tmp[(size_t)e * 2 * nh + nh + h];
+      }
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        g2[0][c] += gsv[c] * q[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+        g2[1][c] += gm[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * av[c];
       }
     }
     node_reduce<V, 2, WPN>(g2, smem, lane, sub);
@@ -697,9 +736,13 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_Q(
       float k[V], pk[V];
       ldrow<V>(qkv + (size_t)j * 3 * H + H, lane, k);
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
-      const float gsat = sat_tmp[(size_t)e * 2 * nh + lane / lph];
+      bool any_heads = false;
+      if constexpr (GEN) any_heads = D.hgen != 0;
 #pragma unroll
-      for (int c = 0; c < V; ++c) gq[0][c] += gsat * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+      for (int c = 0; c < V; ++c) {
+        const float gsat = sat_tmp[(size_t)e * 2 * nh + (any_heads ? (lane * V + c) / D.hd : lane / lph)];
+        gq[0][c] += gsat * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+      }
     }
     node_reduce<V, 1, WPN>(gq, smem, lane, sub);
     if (sub == 0) strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq[0]);
@@ -1058,7 +1101,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
 #define VSN_LAUNCH_ACT(KN, RK, ...)                                                                     \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
-    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;                               \
     VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KN,                                                            \
                      <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
   } while (0)
@@ -1085,7 +1128,7 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
   if (g_split_channels && (V & 1) == 0 && D.S == 8 && (pick_wpn(D.N) == 1 || g_split_channels > 1)) {
     // two waves per node, half the channels each (see the kernel)
     const int w = pick_wpn(D.N);
-    const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+    const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
     const dim3 grid(node_grid(D.N, w), 2);
     const size_t lds = node_lds(w, D.S, V / 2);
 #define VSN_EUT(VH)                                                                                                   \
@@ -1120,7 +1163,7 @@ int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const floa
                    float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
                    float* g_vh, bool with_edge_update) {
   const int w = pick_wpn(D.N);
-  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   const int with_eu = with_edge_update ? 1 : 0;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf1,
                    <<<(with_eu ? 4 : 2) * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
@@ -1131,7 +1174,7 @@ int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float*
                    float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts,
                    const float* vp, const float* g_f, float* g_vp) {
   const int w = pick_wpn(D.N);
-  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf2,
                    <<<2 * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
                        D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp));
@@ -1149,7 +1192,7 @@ int launch_bwd_side(hipStream_t st, const Dims& D, const float* vp, const float*
     VSN_LAUNCH_ACT(k_bwd_vecmsg_S, D.S, D, g_vec, tpre, g_vh);
     return 0;
   }
-  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_side,
                    <<<3 * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
                        D, vp, pe, g_f, g_pe, g_vp, g_geo, g_vec, tpre, g_vh));

@@ -292,14 +292,28 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
       ldrow<V>(qkv + (size_t)j * 3 * H + 2 * H, lane, v);
       ldrow<V>(pe + (size_t)e * 3 * H, lane, pk);
       ldrow<V>(pe + (size_t)e * 3 * H + H, lane, pv);
-      float part = 0.f;
+      float av[V];  // the attention weight of the head of each of the lane's channels
+      bool any_heads = false;
+      if constexpr (GEN) any_heads = D.hgen != 0;
+      if (any_heads) {  // head count that does not divide 64: a lane's channels may straddle heads
+        float pc[V], sc[V];
 #pragma unroll
-      for (int c = 0; c < V; ++c) part += q[c] * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
-      const float sat = group_sum(part, lph);
-      const float a = act_f((GEN ? D.attn_act : VSN_ACT_SILU), sat) * C;
+        for (int c = 0; c < V; ++c) pc[c] = q[c] * k[c] * act_f(D.act, pk[c]);
+        head_sums_any<V>(pc, lane, D.hd, D.nh, sc);
+#pragma unroll
+        for (int c = 0; c < V; ++c) av[c] = act_f(D.attn_act, sc[c]) * C;
+      } else {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < V; ++c) part += q[c] * k[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pk[c]);
+        const float sat = group_sum(part, lph);
+        const float a = act_f((GEN ? D.attn_act : VSN_ACT_SILU), sat) * C;
+#pragma unroll
+        for (int c = 0; c < V; ++c) av[c] = a;
+      }
 #pragma unroll
       for (int c = 0; c < V; ++c) {
-        mv[c] = v[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * a;
+        mv[c] = v[c] * act_f((GEN ? D.act : VSN_ACT_SILU), pv[c]) * av[c];
         acc[0][c] += mv[c];
       }
       strow<V>(m + (size_t)e * H, lane, mv);
@@ -561,14 +575,14 @@ VSN_KL(k_node_update);
 #define VSN_LAUNCH_ACT_TIMED(KN, RK, ...)                                                               \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
-    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;                     \
     VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KL_##KN,                                                       \
                      ::go(node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st, __VA_ARGS__)); \
   } while (0)
 #define VSN_LAUNCH_ACT(KN, RK, ...)                                                                     \
   do {                                                                                                  \
     const int w__ = pick_wpn(D.N);                                                                      \
-    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;                               \
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;                     \
     VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KN,                                                            \
                      <<<node_grid(D.N, w__), node_block(w__), node_lds(w__, (RK), D.H / 64), st>>>(__VA_ARGS__)); \
   } while (0)
@@ -609,7 +623,7 @@ int launch_edge_attn_update(hipStream_t st, const Dims& D, const float* qkv, con
                             const float* vp, float* f) {
   if (D.N <= 0) return 0;
   const int w__ = pick_wpn(D.N);
-  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
+  const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   VSN_DISPATCH_VSA(D.H, D.S, w__, g__, KL_k_edge_attn_update,
                    ::go(2 * node_grid(D.N, w__), node_block(w__), node_lds(w__, 1, D.H / 64), st, D, qkv, pe, m, A,
                         vp, f));

@@ -51,6 +51,11 @@ CASES = {
     "h512_l3": (dict(embedding_dimension=512, num_layers=3), 27, 117, [22, 12, 33]),
     # reduce_op = "mean" (visnet.py:146): per-fragment mean of the atomic terms; an empty fragment in the batch
     "h64_l2_mean": (dict(embedding_dimension=64, num_layers=2, reduce_op="mean"), 28, 118, [22, 0, 12, 31]),
+    # head counts that do not divide 64 (the reference asks only hidden % num_heads == 0, visnet_block.py:158-166):
+    # 3 heads of 64 channels at 3 channels per lane (a lane's channels straddle heads), 5 heads, 12 heads of 16
+    "h192_l2_heads3": (dict(embedding_dimension=192, num_layers=2, num_heads=3), 29, 119, [22, 12, 27]),
+    "h320_l2_heads5": (dict(embedding_dimension=320, num_layers=2, num_heads=5, activation="ssp"), 30, 120, [24, 12]),
+    "h192_l3_heads12": (dict(embedding_dimension=192, num_layers=3, num_heads=12), 31, 121, [30, 12, 19]),
 }
 
 
