@@ -50,7 +50,7 @@ typedef struct vsn_hparams {
   int32_t hidden;            /* embedding_dimension: a multiple of 64, 64..512 */
   int32_t num_layers;        /* num_layers                                     */
   int32_t num_rbf;           /* num_rbf                                        */
-  int32_t num_heads;         /* power of two dividing 64                       */
+  int32_t num_heads;         /* <= 64, dividing hidden (visnet_block.py:158-166)   */
   int32_t lmax;              /* 1 | 2                                          */
   int32_t max_z;             /* embedding rows                                 */
   int32_t max_num_neighbors; /* radius_graph truncation (incl. the self loop)  */
