@@ -264,3 +264,37 @@ def test_preprocessed_order_rejects_unknown_atoms():
                      np.array([6, 6, 8, 1, 1, 1]), np.zeros((6, 3)))
     with pytest.raises(ValueError):
         preprocessed_order(p)
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed with the round's profiles (profiles/r*_bench_line.json, printed by bench.py on the GPU
+    box) carries what the measurement contract asks for: BASELINE's metric and unit, the 1000-step Chignolin loop, a
+    roofline block for the dominant GEMM with the scatter path nested as roofline.hbm, a CPU baseline that timed the
+    REFERENCE's model with the node's physical core count, no model keys in config, and the split mode only as a
+    labelled secondary."""
+    import glob
+    import json
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    assert d["metric"] == "MD steps/sec on Chignolin" and d["unit"] == "steps/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] >= 1000 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["requested_run"]["steps"] == d["steps_requested"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] == 157.3 and 0.3 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0)
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0
+    assert abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9
+    if "rocprof" in h:  # live dispatch timestamps agree with the committed kernel trace of the same build
+        assert 0.9 < h["rocprof"]["live_over_trace"] < 1.1 and h["avg_launch_us"] >= h["rocprof"]["min_us"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["unit"] == "force evaluations/s" and c["physical_cores"] >= 1
+    assert c["cores"] >= 1 and "reference_layout" in c["layouts"] and c["value"] > 0
+    assert c["layouts"]["reference_layout"]["threads_per_partition"] == max(1, c["physical_cores"] // 2)
+    modes = [s_ for s_ in d["secondary"] if "gemm_split3" in s_["metric"]]
+    assert modes and all("parity" in s_ and "split" in s_["dtype"] for s_ in modes)
+    assert "gemm_split3" not in d["metric"]
