@@ -56,6 +56,9 @@ CASES = {
     "h192_l2_heads3": (dict(embedding_dimension=192, num_layers=2, num_heads=3), 29, 119, [22, 12, 27]),
     "h320_l2_heads5": (dict(embedding_dimension=320, num_layers=2, num_heads=5, activation="ssp"), 30, 120, [24, 12]),
     "h192_l3_heads12": (dict(embedding_dimension=192, num_layers=3, num_heads=12), 31, 121, [30, 12, 19]),
+    # the generic-head path with lmax = 1 (S = 3), the mean reduction and an rms VecLayerNorm at once
+    "h192_l2_heads6_lmax1_mean_rms": (dict(embedding_dimension=192, num_layers=2, num_heads=6, lmax=1, reduce_op="mean",
+                                       vecnorm_type="rms"), 32, 122, [28, 12, 0, 22]),
 }
 
 

@@ -27,7 +27,7 @@ def load_golden(name):
 GOLDEN_CASES = ["h64_l2", "h128_l3_lmax1", "h64_l2_trunc", "h256_l9_default", "h64_l3_rms", "h64_l3_maxmin",
                 "h64_l2_whole", "h64_l2_gauss", "h128_l2_gauss_lmax1", "h64_l2_ssp", "h64_l2_tanh_sig",
                 "h128_l2_sig_swish", "h192_l2", "h320_l2_rms", "h384_l2_lmax1", "h448_l2", "h512_l3", "h64_l2_mean",
-                "h192_l2_heads3", "h320_l2_heads5", "h192_l3_heads12"]
+                "h192_l2_heads3", "h320_l2_heads5", "h192_l3_heads12", "h192_l2_heads6_lmax1_mean_rms"]
 HIP_CASES = list(GOLDEN_CASES)
 
 
