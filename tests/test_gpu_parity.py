@@ -463,6 +463,27 @@ def test_batch_path_other_head_counts(lib_built, nh):
         m.engine.set_option("fuse_panel", 1)
 
 
+@pytest.mark.parametrize("nh", [3, 6, 12])
+def test_batch_path_head_counts_that_do_not_divide_64(lib_built, nh):
+    """the generic per-head sums (Dims::hgen, head_sums_any) on the BATCH path (N >= 4096: one wave per node; the
+    fused panel products are bypassed for these head counts): replica 0 of a tiled batch against the fp64 oracle,
+    every replica bit-identical to it"""
+    hp = default_hparams(embedding_dimension=192, num_layers=2, num_heads=nh)
+    z1, p1, s1, e1 = random_fragments(21, [25, 12, 35])
+    reps = 60
+    n1 = len(z1)
+    z = np.tile(z1, reps)
+    pos = np.tile(p1, (reps, 1))
+    start = np.concatenate([s1 + r * n1 for r in range(reps)])
+    end = np.concatenate([e1 + r * n1 for r in range(reps)])
+    assert len(z) >= 4096
+    m = model_for(hp, 11)
+    E64, F64, _ = ViSNetOracle(hp, make_state_dict(hp, seed=11), torch.float64).energy_forces(z1, p1, s1, e1)
+    e, f = m.dl_potential_loader(frag(z, pos, start, end))
+    check(e.reshape(reps, -1)[0].reshape(-1, 1), f.reshape(reps, n1, 3)[0], E64, F64)
+    assert np.array_equal(f.reshape(reps, n1, 3), np.broadcast_to(f.reshape(reps, n1, 3)[0], (reps, n1, 3)))
+
+
 @pytest.mark.parametrize("acts", [None, ("ssp", "tanh")])
 def test_batch_path_option_matrix(lib_built, acts):
     """Fragment batch (N >= 4096, hidden 256: one wave per node, panel / fused products): the A/B switches of the
