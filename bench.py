@@ -73,6 +73,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", default="chig_md", choices=["chig_md", "trpcage_md", "ww_md", "abd_md",
                                                                "frag_batch", "frag_stream"])
     ap.add_argument("--frags-per-gpu", type=int, default=4096)
+    ap.add_argument("--conformations", type=int, default=1_000_000,
+                    help="frag_stream: total NEW conformations over all ranks (BASELINE configs[4]: 1M)")
     ap.add_argument("--min-seconds", type=float, default=0.0,
                     help="tuning aid (default off): stretch the timed region to at least this long, "
                          "steps = max(--steps, ceil(min_seconds / step time))")
@@ -471,18 +473,10 @@ def run_frag_batch(ctx, eng, hp, args, steps, warmup):
     dev = ctx.dev
     H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
     rng = np.random.default_rng(1234 + ctx.rank)
-    pool, ref_e, ref_f = [], [], []
-    for pname in ("chig", "trpcage", "ww", "abd"):
-        g = load_golden(pname)
-        ib = 0
-        for b in range(len(g["start"])):
-            a0, a1 = int(g["start"][b]), int(g["end"][b])
-            if a1 == a0:
-                continue
-            pool.append((g["z"][a0:a1], g["pos_placed"][a0:a1]))
-            ref_e.append(g["E_ref64_placed"][ib])
-            ref_f.append(g["F_ref64_placed"][a0:a1])
-            ib += 1
+    hv = harvested_pool()
+    pool = [(z_, p_) for z_, p_, _, _ in hv]
+    ref_e = [np.asarray([e_]) for _, _, e_, _ in hv]
+    ref_f = [f_ for _, _, _, f_ in hv]
     zs, ps, sizes = [], [], []
     for i in range(args.frags_per_gpu):
         zf, pf = pool[i % len(pool)]
@@ -530,34 +524,59 @@ def run_frag_batch(ctx, eng, hp, args, steps, warmup):
                 parity=par, roofline=dict(roof, **({"hbm": roof_hbm} if roof_hbm else {})))
 
 
-def run_frag_stream(ctx, eng, hp, args, nbatch=64):
-    """BASELINE configs[4] as stated (Protein Unit Dataset throughput): every step evaluates a NEW batch of
-    conformations.  `nbatch` distinct batches (fragment pool of the four example proteins, 0.05 A jitter with its own
-    seed per batch) sit in pinned host memory; per step the next batch's z / pos go H2D on a copy stream into the
-    other of two device buffers while the current batch is evaluated, and its energies / forces come back D2H into
-    pinned buffers - all inside the timed region.  Reported as a `secondary` (PCIe-inclusive; never `value`)."""
-    dev = ctx.dev
-    rng = np.random.default_rng(4321 + ctx.rank)
+def harvested_pool():
+    """the 220 non-empty dipeptide / ACE-NME fragments of the four example proteins with the reference-source golden
+    of each: [(z, pos, E64, F64)]"""
     pool = []
     for pname in ("chig", "trpcage", "ww", "abd"):
         g = load_golden(pname)
+        ib = 0
         for b in range(len(g["start"])):
             a0, a1 = int(g["start"][b]), int(g["end"][b])
             if a1 > a0:
-                pool.append((g["z"][a0:a1], g["pos_placed"][a0:a1]))
+                pool.append((g["z"][a0:a1], g["pos_placed"][a0:a1], float(np.asarray(g["E_ref64_placed"][ib]).reshape(-1)[0]),
+                             g["F_ref64_placed"][a0:a1]))
+                ib += 1
+    return pool
+
+
+def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16):
+    """BASELINE configs[4] as stated - "Protein Unit Dataset throughput: 1M dipeptide conformations batched across
+    the GPUs (pure force eval, no integrator)": `conformations` (default 1 000 000 over all ranks) NEW conformations,
+    every one evaluated exactly once, in batches of --frags-per-gpu per rank.  Conformation = a fragment of the
+    harvested pool (220 dipeptides / ACE-NMEs of the four example proteins) centred, + N(0, 0.05 A) jitter drawn from
+    default_rng(1234 + rank).  All batches sit in pinned host memory; per step the next batch's z / pos go H2D on a
+    copy stream into the other of two device buffers while the current batch is evaluated, and its energies / forces
+    come back D2H into pinned buffers and are CONSUMED on the host (running float64 checksums of E and F) - all inside
+    the timed region, PCIe-inclusive.  Every `golden_every`-th batch keeps the golden geometry in its first 220
+    fragments and those results are compared with the reference-source golden (parity inside the stream).
+    Reported as a `secondary`; never `value`."""
+    dev = ctx.dev
+    H, L, S, R = hp["embedding_dimension"], hp["num_layers"], 8, hp["num_rbf"]
+    rng = np.random.default_rng(1234 + ctx.rank)
+    pool = harvested_pool()
     nf = args.frags_per_gpu
-    sizes = np.asarray([len(pool[i % len(pool)][0]) for i in range(nf)])
+    total = int(conformations if conformations is not None else args.conformations)
+    nbatch = max(2, -(-total // (nf * ctx.world)))
+    frs = [pool[i % len(pool)] for i in range(nf)]
+    sizes = np.asarray([len(fr[0]) for fr in frs])
     end = np.cumsum(sizes)
     start = end - sizes
     natoms = int(end[-1])
-    z_h = torch.empty(nbatch, natoms, dtype=torch.int64).pin_memory()
+    ng = min(len(pool), nf)
+    ngat = int(end[ng - 1])
+    z_all = np.concatenate([fr[0] for fr in frs])
+    p_ctr = np.concatenate([fr[1] - fr[1].mean(0) for fr in frs]).astype(np.float32)
+    p_gold = np.concatenate([fr[1] for fr in frs[:ng]]).astype(np.float32)
+    E_gold = np.asarray([fr[2] for fr in frs[:ng]])
+    F_gold = np.concatenate([fr[3] for fr in frs[:ng]])
+    z_h = torch.as_tensor(z_all).pin_memory()   # (same fragment layout every batch: one host copy, uploaded every step)
     p_h = torch.empty(nbatch, natoms, 3, dtype=torch.float32).pin_memory()
-    frs = [pool[i % len(pool)] for i in range(nf)]
-    z_all = np.concatenate([zf for zf, _ in frs])
-    p_all = np.concatenate([pf - pf.mean(0) for _, pf in frs]).astype(np.float32)
-    for bi in range(nbatch):  # same fragment layout, its own 0.05 A jitter per batch = a new conformation of every fragment
-        z_h[bi] = torch.as_tensor(z_all)
-        p_h[bi] = torch.as_tensor(p_all + rng.normal(0, 0.05, size=p_all.shape).astype(np.float32))
+    pn = p_h.numpy()
+    for bi in range(nbatch):
+        pn[bi] = p_ctr + np.float32(0.05) * rng.standard_normal(p_ctr.shape, dtype=np.float32)
+        if bi % golden_every == 0:
+            pn[bi, :ngat] = p_gold
     e_h = torch.empty(2, nf, dtype=torch.float32).pin_memory()
     f_h = torch.empty(2, natoms, 3, dtype=torch.float32).pin_memory()
     zd = [torch.empty(natoms, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -569,14 +588,32 @@ def run_frag_stream(ctx, eng, hp, args, nbatch=64):
     up = [torch.cuda.Event() for _ in range(2)]      # H2D of buffer b complete
     free = [torch.cuda.Event() for _ in range(2)]    # evaluation that read buffer b complete
     down = [torch.cuda.Event() for _ in range(2)]    # D2H of result buffer b complete
-    state = dict(i=0)
+    state = dict(i=0, sumE=0.0, sumF=0.0, sumF2=0.0, consumed=0, gold=0, gold_dF=0.0, gold_dE=0.0, held=[None, None])
 
     def upload(bi, b):
         with torch.cuda.stream(copy):
             copy.wait_event(free[b])
-            zd[b].copy_(z_h[bi % nbatch], non_blocking=True)
+            zd[b].copy_(z_h, non_blocking=True)
             pd[b].copy_(p_h[bi % nbatch], non_blocking=True)
             up[b].record(copy)
+
+    def consume(b):
+        """host side of the stream: the results of the batch held in result buffer b have landed"""
+        bi = state["held"][b]
+        if bi is None:
+            return
+        down[b].synchronize()
+        e_, f_ = e_h[b].numpy(), f_h[b].numpy()
+        state["sumE"] += float(e_.sum(dtype=np.float64))
+        state["sumF"] += float(np.abs(f_).sum(dtype=np.float64))
+        state["sumF2"] += float(np.square(f_, dtype=np.float64).sum())
+        state["consumed"] += 1
+        if bi % golden_every == 0 and bi < nbatch:
+            pr = parity_check(f"streamed batch {bi}, golden block", e_[:ng], f_[:ngat], E_gold, F_gold)
+            state["gold"] += 1
+            state["gold_dF"] = max(state["gold_dF"], pr["max_dF"])
+            state["gold_dE"] = max(state["gold_dE"], pr["max_dE"])
+        state["held"][b] = None
 
     for b in range(2):
         free[b].record(main)
@@ -588,7 +625,7 @@ def run_frag_stream(ctx, eng, hp, args, nbatch=64):
         b = i & 1
         upload(i + 1, b ^ 1)                      # next batch flies while this one is evaluated
         main.wait_event(up[b])
-        down[b].synchronize()                     # host: result buffer b of two steps ago has landed (consumable)
+        consume(b)                                # result buffer b (batch i - 2) is read before it is overwritten
         eng.forces_device(zd[b], pd[b], start, end, ed[b], fd[b])
         free[b].record(main)
         with torch.cuda.stream(copy):
@@ -596,20 +633,45 @@ def run_frag_stream(ctx, eng, hp, args, nbatch=64):
             e_h[b].copy_(ed[b], non_blocking=True)
             f_h[b].copy_(fd[b], non_blocking=True)
             down[b].record(copy)
+        state["held"][b] = i
         state["i"] = i + 1
 
-    steps = max(nbatch, args.steps if args.workload == "frag_stream" else nbatch)
-    k, el = timed_region(ctx, step, steps, 2, 0.0)
+    # warm-up outside the clock: two batches through the same pipe, their results discarded, counters reset
+    step()
+    step()
     copy.synchronize()
-    assert torch.isfinite(f_h).all() and torch.isfinite(e_h).all()
+    torch.cuda.synchronize()
+    state.update(i=0, sumE=0.0, sumF=0.0, sumF2=0.0, consumed=0, gold=0, gold_dF=0.0, gold_dE=0.0, held=[None, None])
+    upload(0, 0)
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(nbatch):
+        step()
+    consume(0)
+    consume(1)
+    copy.synchronize()
+    ctx.barrier()
+    el = ctx.max_over_ranks(time.perf_counter() - t0)
+    k = nbatch
+    assert state["consumed"] == nbatch and math.isfinite(state["sumE"]) and math.isfinite(state["sumF"])
     ms = 1e3 * el / k
+    E_tot = count_edges(pn[0], start, end, hp["cutoff"], hp["max_num_neighbors"])
+    flops_batch = 2.0 * fwd_flops(natoms, E_tot, H, L, S, R)
     return dict(metric="fragment-batch forces/sec, streamed conformations (Protein Unit Dataset throughput)",
                 value=k * nf * ctx.world / el, unit="fragments/s", steps=k, ms_per_step=ms, scaling="weak",
-                config=dict(workload=(f"{k} steps over {nbatch} DISTINCT batches of {nf} dipeptide/ACE-NME fragments per "
-                                      f"GPU ({natoms} atoms each): pinned host buffers, double-buffered H2D of z/pos on a "
-                                      f"copy stream, D2H of E/F, all inside the timed region (PCIe-inclusive)"),
+                parity=dict(max_dF=state["gold_dF"], max_dE=state["gold_dE"], golden_blocks_checked=state["gold"],
+                            max_dF_over_ranks=ctx.max_over_ranks(state["gold_dF"])),
+                config=dict(workload=(f"{k * nf * ctx.world} NEW dipeptide/ACE-NME conformations, each evaluated once: {k} "
+                                      f"batches of {nf} per GPU ({natoms} atoms, ~{E_tot} edges each), default_rng(1234 + "
+                                      f"rank), 0.05 A jitter; pinned host buffers, double-buffered H2D of z/pos on a copy "
+                                      f"stream, D2H of E/F consumed on the host (checksums), all inside the timed region "
+                                      f"(PCIe-inclusive); golden block re-checked every {golden_every}th batch"),
+                            conformations=k * nf * ctx.world, seconds=el,
                             atoms_per_gpu=natoms, atoms_per_s=k * natoms * ctx.world / el,
-                            distinct_batches=nbatch, h2d_bytes_per_step=natoms * 20, d2h_bytes_per_step=natoms * 12 + nf * 4))
+                            gflops=k * flops_batch * ctx.world / el / 1e9,
+                            checksum=dict(sum_E=state["sumE"], sum_absF=state["sumF"], sum_F2=state["sumF2"],
+                                          note="rank 0's batches, float64 accumulation on the host"),
+                            h2d_bytes_per_step=natoms * 20, d2h_bytes_per_step=natoms * 12 + nf * 4))
 
 
 def _cpu_evaluator(hp, sd):
@@ -675,7 +737,7 @@ def cpu_baseline_md(plan, prot, hp, sd):
     (i)  the reference's LITERAL CPU configuration: two fragment partitions evaluated by two Python threads on one
          shared model with torch.set_num_threads(physical_cores // 2) (device_strategy.py:176,252-263;
          physical cores from lscpu as utils/system.py:28-45 counts them);
-    (ii) one partition at the best of 8 / 16 / 32 intra-op threads, and the two-partition layout at half of that
+    (ii) one partition at the best of 8 / 16 / 32 intra-op threads
          (torch's intra-op threading saturates early on these small tensors: a 128-core host runs the literal
          layout several times SLOWER than 16 threads).
     Protocol: 2 warm-up, 5 timed evaluations, median.  `value` = the fastest layout (the most
@@ -722,22 +784,19 @@ def cpu_baseline_md(plan, prot, hp, sd):
     r, n = _median_rate(one, budget_s=25.0)
     layouts["single_partition_best_of_8_16_32"] = dict(partitions=1, threads_per_partition=best_nt, threads=best_nt,
                                                        evals_per_s=r, timed_evaluations=n)
-    nt2 = max(1, best_nt // 2)
-    if nt2 != nt_ref:
-        torch.set_num_threads(nt2)
-        r, n = _median_rate(both, budget_s=25.0)
-        layouts["two_partitions_at_half_of_best"] = dict(partitions=2, threads_per_partition=nt2, threads=2 * nt2,
-                                                         evals_per_s=r, timed_evaluations=n)
     pool.shutdown()
     win = max(layouts, key=lambda k_: layouts[k_]["evals_per_s"])
     return dict(value=layouts[win]["evals_per_s"], unit="force evaluations/s", cores=layouts[win]["threads"], kind=kind,
                 physical_cores=phys, host_hw_threads=ncpu, layout_of_value=win, layouts=layouts,
                 reference_layout_evals_per_s=layouts["reference_layout"]["evals_per_s"], source=origin,
                 protocol="2 warm-up + 5 timed evaluations per layout, median (BASELINE.md section 3)",
+                sample_short=(f"{kind} ViSNet model, fp32, energy+force evaluations of the Chignolin fragment batch "
+                              f"(B={len(plan.start)}, N={len(plan.z)}); 2 warm-up + 5 timed, median; force evaluation only "
+                              f"(GPU value = full MD step); {phys} physical cores"),
                 sample=f"energy+force evaluations of the Chignolin fragment batch (B={len(plan.start)}, "
                        f"N={len(plan.z)}), fp32, by {origin}; layouts: the reference's literal CPU configuration "
                        f"(2 partitions x {nt_ref} = physical_cores // 2 threads, device_strategy.py:176,252-263), one "
-                       f"partition at {best_nt} threads (best of 8/16/32), two partitions x {nt2}; on a host with "
+                       f"partition at {best_nt} threads (best of 8/16/32); on a host with "
                        f"{phys} physical cores / {ncpu} hardware threads; force evaluation only (cap-hydrogen "
                        f"relaxation and integrator excluded)")
 
@@ -805,6 +864,21 @@ def main():
                 for _ in range(50):
                     seam.dl_potential_loader(fd)
                 res["config"]["host_seam_evals_per_s_pcie_inclusive"] = 50 / (time.perf_counter() - t1)
+                # what north_star literally describes: the reference-shaped calculator call, host numpy in and out -
+                # DLBondedCalculator(prot) = DistanceFragment.get_fragments (cap-H placement + L-BFGS on the device,
+                # fragments back to the host) + the seam + DipeptideBondedCombiner on the host (bonded.py:102-123)
+                from ai2bmd_amd.bonded import DLBondedCalculator
+                from ai2bmd_amd.distancefrag import DistanceFragment
+
+                calc = DLBondedCalculator.from_models([seam], fragment_method=DistanceFragment(device=ctx.dev))
+                calc.fragment_method.fragment(prot)
+                for _ in range(5):
+                    calc(prot)
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    calc(prot)
+                res["config"]["reference_shaped_step_calls_per_s"] = 50 / (time.perf_counter() - t1)
+                del calc
             if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
                 cpu = cpu_baseline_md(plan, prot, hp, sd)
             del md
@@ -815,7 +889,7 @@ def main():
         if not args.no_secondary and not args.emulate_shard and args.workload == "chig_md":
             # the rest of BASELINE.json's metric in the same line: fragment-batch forces/s (weak scaling, no
             # collective), Trp-cage (configs[2]) and, sharded over N > 1 GPUs, the WW domain (configs[3])
-            extra_md = ["trpcage"] + (["ww"] if ctx.world > 1 else [])
+            extra_md = ["trpcage", "ww"]  # (WW at N = 1 as well: the 1-GPU anchor of the sharded curve)
             for pname in extra_md:
                 r2, keep = run_md(ctx, eng, hp, pname, args, 400 if pname == "trpcage" else 300, 10)
                 del keep
@@ -887,12 +961,128 @@ def main():
                                  **({"parity_max_dF": r["parity"]["max_dF_over_ranks"]} if "parity" in r else {}),
                                  **({"parity": r["parity"], "dtype": r["dtype"]} if r.get("keep_parity") else {}),
                                  **({k_: r[k_] for k_ in ("roofline",) if r.get(k_)})) for r in secondary]
-        # the driver keeps `config` whole: one compact line per secondary metric rides there too
-        out["config"]["secondary_summary"] = {r["metric"]: dict(value=r["value"], unit=r["unit"], steps=r["steps"],
-                                                                ms_per_step=r["ms_per_step"]) for r in secondary}
     if ctx.rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the ONE line the driver parses: compact by construction (a 23 KB line was not parsed)
+# ------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 6000  # bytes; the driver keeps an 8 KB tail of stdout
+
+
+def _short(v, sig=6, smax=240):
+    """floats to `sig` significant digits, long strings cut, recursively"""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if math.isfinite(v) else None
+    if isinstance(v, str):
+        return v if len(v) <= smax else v[: smax - 1] + "~"
+    if isinstance(v, dict):
+        return {k: _short(x, sig, smax) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x, sig, smax) for x in v]
+    return _short(float(v), sig, smax) if hasattr(v, "__float__") else str(v)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+SECONDARY_KEYS = {  # metric of a secondary -> short key in config.secondary_summary
+    "MD steps/sec on Trp-cage": "trpcage_md",
+    "MD steps/sec on WW domain": "ww_md",
+    "fragment-batch forces/sec": "frag_batch",
+    "fragment-batch forces/sec, streamed conformations (Protein Unit Dataset throughput)": "frag_stream_pcie",
+    "MD steps/sec on Chignolin + MM non-bonded": "chig_md_mm",
+    "MD steps/sec on Chignolin (small variant H=128 L=6)": "chig_md_h128l6",
+    "MD steps/sec on Chignolin (opt-in mode gemm_split3)": "chig_md_split3_optin",
+    "fragment-batch forces/sec (opt-in mode gemm_split3)": "frag_batch_split3_optin",
+}
+
+
+def compact_line(full: dict, detail_path: str | None = None, limit: int = LINE_LIMIT) -> dict:
+    """The result line: everything the measurement contract names, nothing nested deeper than it has to be.  The full
+    record (every secondary's own roofline, every CPU layout, every scatter kernel) goes to `detail_path`."""
+    c = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "steps_requested", "warmup", "ms_per_step",
+                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks", "backend"))
+    cfg = full.get("config", {})
+    cc = _pick(cfg, ("workload", "edges_local", "frag_atoms_local", "algorithmic_gflop_per_step_local",
+                     "host_seam_evals_per_s_pcie_inclusive", "reference_shaped_step_calls_per_s",
+                     "reference_caller_on_hip_seam_calls_per_s", "step_bound_ms"))
+    if "requested_run" in cfg:
+        cc["requested_run"] = _pick(cfg["requested_run"], ("steps", "ms_per_step", "value", "unit"))
+    summ = {}
+    for r in full.get("secondary", []):
+        key = SECONDARY_KEYS.get(r["metric"], r["metric"])
+        e = _pick(r, ("value", "unit", "steps", "ms_per_step"))
+        rf = r.get("roofline") or {}
+        if "frac" in rf:
+            e["mfma_frac"] = rf["frac"]
+        if isinstance(rf.get("hbm"), dict) and "frac" in rf["hbm"]:
+            e["hbm_frac"] = rf["hbm"]["frac"]
+        if "parity_max_dF" in r:
+            e["max_dF"] = r["parity_max_dF"]
+        e.update(_pick(r.get("config", {}), ("conformations", "atoms_per_s", "gflops", "checksum")))
+        summ[key] = e
+    if summ:
+        cc["secondary_summary"] = summ
+    c["config"] = cc
+    if "roofline" in full:
+        r = full["roofline"]
+        cr = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                       "avg_launch_us", "algorithmic_flop_per_launch", "algorithmic_bytes_per_launch", "step_frac",
+                       "step_tflops"))
+        if isinstance(r.get("hbm"), dict):
+            h = r["hbm"]
+            ch = _pick(h, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step",
+                           "avg_launch_us", "algorithmic_bytes_per_launch"))
+            if "rocprof" in h:
+                ch["rocprof"] = _pick(h["rocprof"], ("avg_us", "frac_from_trace", "live_over_trace"))
+            cr["hbm"] = ch
+        if isinstance(r.get("reverse_walks"), dict):
+            cr["reverse_walks"] = r["reverse_walks"]
+        c["roofline"] = cr
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        c["cpu_baseline"] = _pick(b, ("value", "unit", "cores", "kind", "physical_cores", "host_hw_threads",
+                                      "layout_of_value", "reference_layout_evals_per_s", "source", "sample_short"))
+        c["cpu_baseline"]["sample"] = c["cpu_baseline"].pop("sample_short", None) or b.get("sample", "")
+    if "parity" in full:
+        c["parity"] = _pick(full["parity"], ("max_dE", "max_dF", "force_mae", "max_abs_F", "pipeline_max_dF",
+                                             "max_dF_over_ranks"))
+    if detail_path:
+        c["full_detail"] = detail_path
+    c = _short(c)
+    # belt and braces: never exceed the limit - drop the least essential pieces in order until it fits
+    for drop in (("config", "secondary_summary", "frag_batch_split3_optin"), ("roofline", "reverse_walks"),
+                 ("config", "secondary_summary", "chig_md_split3_optin"), ("data",), ("config", "secondary_summary")):
+        if len(json.dumps(c, separators=(",", ":"))) <= limit:
+            break
+        d = c
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return c
+
+
+def emit(full: dict, args) -> None:
+    """full record -> gpurun_out/ (scratch; copied into profiles/ by tools/profile_round.sh) and ONE stderr line;
+    compact line -> the LAST line of stdout."""
+    path = None
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        path = os.path.join("gpurun_out", f"bench_full_{args.workload}_n{full['n_gpus']}.json")
+        with open(os.path.join(ROOT, path), "w") as fh:
+            json.dump(full, fh)
+    except OSError:
+        path = None
+    print("BENCH_FULL_DETAIL (not the result line) " + json.dumps(full), file=sys.stderr, flush=True)
+    line = json.dumps(compact_line(full, path), separators=(",", ":"))
+    assert len(line) <= LINE_LIMIT and "\n" not in line, len(line)
+    print(line, flush=True)
 
 
 if __name__ == "__main__":

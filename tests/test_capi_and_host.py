@@ -266,35 +266,77 @@ def test_preprocessed_order_rejects_unknown_atoms():
         preprocessed_order(p)
 
 
-def test_committed_bench_line_keeps_the_contract():
-    """The bench line committed with the round's profiles (profiles/r*_bench_line.json, printed by bench.py on the GPU
-    box) carries what the measurement contract asks for: BASELINE's metric and unit, the 1000-step Chignolin loop, a
-    roofline block for the dominant GEMM with the scatter path nested as roofline.hbm, a CPU baseline that timed the
-    REFERENCE's model with the node's physical core count, no model keys in config, and the split mode only as a
-    labelled secondary."""
-    import glob
-    import json
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
-    assert files
-    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+def _check_result_line(d):
+    """what the measurement contract asks of the ONE line (compact form, bench.compact_line)"""
     assert d["metric"] == "MD steps/sec on Chignolin" and d["unit"] == "steps/s" and d["higher_is_better"] is True
     assert d["n_gpus"] == 1 and d["steps"] >= 1000 and d["dtype"] == "f32" and d["vs_baseline"] is None
-    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-4 * d["value"]
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["config"]["requested_run"]["steps"] == d["steps_requested"]
     r = d["roofline"]
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["peak"] == 157.3 and 0.3 < r["frac"] < 1.0 and (r["traffic"] is None or r["traffic"] > 0)
     h = r["hbm"]
     assert h["bound"] == "hbm" and h["unit"] == "GB/s" and h["peak"] == 8000.0
-    assert abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9
+    assert abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-4
     if "rocprof" in h:  # live dispatch timestamps agree with the committed kernel trace of the same build
-        assert 0.9 < h["rocprof"]["live_over_trace"] < 1.1 and h["avg_launch_us"] >= h["rocprof"]["min_us"]
+        assert 0.9 < h["rocprof"]["live_over_trace"] < 1.1
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["unit"] == "force evaluations/s" and c["physical_cores"] >= 1
-    assert c["cores"] >= 1 and "reference_layout" in c["layouts"] and c["value"] > 0
-    assert c["layouts"]["reference_layout"]["threads_per_partition"] == max(1, c["physical_cores"] // 2)
-    modes = [s_ for s_ in d["secondary"] if "gemm_split3" in s_["metric"]]
-    assert modes and all("parity" in s_ and "split" in s_["dtype"] for s_ in modes)
-    assert "gemm_split3" not in d["metric"]
+    assert c["cores"] >= 1 and c["value"] > 0 and c["sample"] and c["reference_layout_evals_per_s"] > 0
+    summ = d["config"]["secondary_summary"]
+    modes = [k for k in summ if "split3" in k]
+    assert modes and all(k.endswith("_optin") for k in modes) and "split3" not in d["metric"]
+
+
+def test_bench_line_is_compact_and_parseable():
+    """the driver could not parse a 23 KB line.  bench.compact_line turns the full record (here: the
+    round-4 record, 23 KB, seven nested secondaries) into a single line < 6 KB that json round-trips and still carries
+    metric / value / roofline (+ hbm) / cpu_baseline / parity / the secondary summary; the emergency trimming never
+    lets it exceed the limit."""
+    import json
+
+    import bench
+
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    c = bench.compact_line(full, "gpurun_out/bench_full_chig_md_n1.json")
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < 6000 and "\n" not in line and json.loads(line) == c
+    _check_result_line(c)
+    assert c["value"] == pytest.approx(full["value"], rel=1e-5) and c["roofline"]["frac"] == pytest.approx(
+        full["roofline"]["frac"], rel=1e-5)
+    assert set(c["config"]["secondary_summary"]) >= {"trpcage_md", "frag_batch", "frag_stream_pcie", "chig_md_mm",
+                                                     "chig_md_h128l6", "chig_md_split3_optin"}
+    assert "secondary" not in c and "layouts" not in c["cpu_baseline"] and "all_scatter_kernels" not in c["roofline"]["hbm"]
+    # a record blown up far past the limit still yields a line under it
+    fat = json.loads(json.dumps(full))
+    fat["secondary"] = fat["secondary"] + [dict(s_, metric=f"extra metric number {i} " + "x" * 60) for i, s_ in
+                                           enumerate(fat["secondary"] * 6)]
+    assert len(json.dumps(bench.compact_line(fat), separators=(",", ":"))) <= bench.LINE_LIMIT
+    # non-finite values never reach the line
+    bad = json.loads(json.dumps(full))
+    bad["roofline"]["traffic"] = float("nan")
+    assert bench.compact_line(bad)["roofline"]["traffic"] is None
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The bench line committed with the round's profiles (profiles/r*_bench_line.json = the LAST stdout line of
+    bench.py on the GPU box, exactly what the driver parses) is compact and carries what the measurement contract asks
+    for: BASELINE's metric and unit, the 1000-step Chignolin loop, a roofline block for the dominant GEMM with the
+    scatter path nested as roofline.hbm, a CPU baseline that timed the REFERENCE's model with the node's physical core
+    count, no model keys in config, the split mode only as a labelled opt-in secondary."""
+    import glob
+    import json
+
+    import bench
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert files
+    raw = open(files[-1]).read().strip().splitlines()[-1]
+    d = json.loads(raw)
+    if "secondary" in d:  # a full record of rounds <= 4
+        d = bench.compact_line(d)
+    else:
+        assert len(raw) <= bench.LINE_LIMIT
+    _check_result_line(d)
