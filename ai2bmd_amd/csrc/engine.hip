@@ -249,7 +249,9 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->reduce_mean = value != 0;
   } else if (k == "gemm_split3") {
     // opt-in arithmetic mode (default 0 = fp32 MFMA everywhere): the grouped products of single-protein sizes as
-    // 3 x bf16 split products with fp32 accumulation (gemm_s3.h).  Plain launches (batches, read-out) stay fp32.
+    // 3 x bf16 split products with fp32 accumulation (gemm_s3.h).  So do the plain products that take the 128x128 batch
+    // tile (k_gemm3_128: rbf / embedding / read-out / per-layer linears of fragment batches); the fused panel products
+    // (fused.hip) and the 64x64 / split-K plain launches keep their fp32 MFMA kernels.
     c->gemm_split3 = value != 0;
     if (c->gemm_split3 && !c->s3) c->s3 = split3_table_create();
   } else if (k == "overlap") {
@@ -518,6 +520,13 @@ extern "C" int vsn_finalize(vsn_handle c) {
   if (c->warena) {
     hipFree(c->warena);
     c->warena = nullptr;
+  }
+  // the split-3 planes are keyed by weight address in the arena just freed: a re-finalize (vsn_load_weight +
+  // vsn_finalize with new values) may get the SAME addresses back, so the cache of the old weights must go
+  if (c->s3) {
+    hipDeviceSynchronize();
+    split3_table_destroy(c->s3);
+    c->s3 = c->gemm_split3 ? split3_table_create() : nullptr;
   }
   HIPCHK(c, hipMalloc((void**)&c->warena, P.host.size() * sizeof(float)));
   HIPCHK(c, hipMemcpy(c->warena, P.host.data(), P.host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1397,7 +1406,7 @@ extern "C" int vsn_gemm(vsn_handle c, const float* A, int lda, const float* Bt, 
   }
   int rc = launch_gemm((hipStream_t)stream, A, lda, Bt, ldb, C, ldc, bias, M, nullptr, Nc, K, flags);
   set_gemm_splitk_workspace(nullptr, 0);
-  if (rc) return fail(c, rc, "gemm: unsupported shape (K, Nc multiples of 32; lda/ldb multiples of 4)");
+  if (rc) return fail(c, rc, "gemm: unsupported shape (K, Nc multiples of 32; lda/ldb/ldc multiples of 4; A, Bt, C, bias 16-byte aligned)");
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) return fail(c, -5, hipGetErrorString(le));
   return 0;

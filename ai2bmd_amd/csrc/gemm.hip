@@ -456,6 +456,10 @@ int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ld
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags) {
   if (M <= 0) return 0;
   if ((K & 31) || (Nc & 31) || (lda & 3) || (ldb & 3) || (ldc & 3)) return -22;  // (16-byte row pieces everywhere)
+  // the epilogue / accumulate prologue move C and bias as f32x4: 16-byte aligned bases
+  if ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bt) | reinterpret_cast<uintptr_t>(C) |
+       reinterpret_cast<uintptr_t>(bias)) & 15)
+    return -22;
   GemmProfiler::Rec* rec = nullptr;
   if (tl_prof) {
     tl_prof->recs.emplace_back();
@@ -568,7 +572,10 @@ bool gemm_group_ok(const GemmDesc* descs, int n) {
   for (int i = 0; i < n; ++i) {
     const GemmDesc& d = descs[i];
     if (d.M <= 0) continue;
-    if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3)) return false;
+    if ((d.K & 31) || (d.Nc & 63) || (d.lda & 3) || (d.ldb & 3) || (d.ldc & 3)) return false;
+    if ((reinterpret_cast<uintptr_t>(d.A) | reinterpret_cast<uintptr_t>(d.Bt) | reinterpret_cast<uintptr_t>(d.C) |
+         reinterpret_cast<uintptr_t>(d.bias)) & 15)
+      return false;  // (f32x4 epilogue: falls back to launch_gemm, which reports -22)
     if (gemm_variant(d.M, d.Nc) == 0) return false;  // big enough to fill the chip alone
     if (d.flags & 2) return false;                   // silu(A) has its own kernels
   }

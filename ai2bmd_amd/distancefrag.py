@@ -70,7 +70,6 @@ class DistanceFragment:
         prot.fragments_z = plan.z
         prot.fragments_start, prot.fragments_end = plan.start, plan.end
         prot.fragments_batch = make_batch_index(plan.start, plan.end)
-        prot.select_index, prot.origin_index = plan.select_index, plan.origin_index
         prot._vsn_plan = plan  # read by MMNonBondedCalculator.set_parameters (the reference leaves prot.exclude_pair)
         dev = self.device
         if dev is None:
@@ -79,6 +78,14 @@ class DistanceFragment:
             except Exception:
                 dev = "cuda:0"
         self.device = dev
+        # like the reference (distancefrag.py:347-353): the recombination indices are torch tensors on the default
+        # device - what the reference's own DipeptideBondedCombiner (torch_scatter) is handed by its DLBondedCalculator
+        try:
+            idx_dev = DeviceStrategy.get_default_device() if DeviceStrategy._bonded_devices else dev
+        except Exception:
+            idx_dev = dev
+        prot.select_index = torch.as_tensor(np.asarray(plan.select_index, dtype=np.int64)).to(idx_dev)
+        prot.origin_index = torch.as_tensor(np.asarray(plan.origin_index, dtype=np.int64)).to(idx_dev)
         idx = torch.device(dev).index or 0
         L = capi.lib()
         self._L = L

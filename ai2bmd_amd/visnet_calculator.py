@@ -69,6 +69,14 @@ class ViSNetEngine:
         self._check(rc)
         # weights live in HBM as PyTorch-ROCm tensors; the library packs its own fused copies
         self.weights = {}
+        self.load_state_dict(state_dict)
+        if hparams.get("reduce_op", "add") == "mean":  # visnet.py:146: per-fragment mean of the atomic terms
+            self.set_option("reduce_mean", 1)
+
+    def load_state_dict(self, state_dict: dict):
+        """(re)load every tensor and re-pack (vsn_load_weight + vsn_finalize; a handle may be re-finalized with new
+        values of the same shapes - every derived copy, the split-3 planes included, is rebuilt)"""
+        L = self._L
         for name, val in state_dict.items():
             name = re.sub(r"^model\.", "", name)
             if name == "prior_model.initial_atomref":
@@ -80,8 +88,6 @@ class ViSNetEngine:
             self._check(rc)
         torch.cuda.synchronize(self.device)
         self._check(L.vsn_finalize(self._h))
-        if hparams.get("reduce_op", "add") == "mean":  # visnet.py:146: per-fragment mean of the atomic terms
-            self.set_option("reduce_mean", 1)
 
     def _check(self, rc):
         if rc != 0:

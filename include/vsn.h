@@ -126,7 +126,9 @@ int vsn_last_status(vsn_handle h);
 int64_t vsn_debug_read(vsn_handle h, const char* name, int layer, void* host_out, int64_t max_elems);
 
 /* Stand-alone GEMM tap used by the unit tests and the roofline bench:
- * C[M,Nc] (+)= A[M,K] * Bt[Nc,K]^T (+ bias). flags: 1 = accumulate, 2 = silu(A). */
+ * C[M,Nc] (+)= A[M,K] * Bt[Nc,K]^T (+ bias). flags: 1 = accumulate, 2 = silu(A).
+ * K and Nc multiples of 32; lda, ldb, ldc multiples of 4 floats; A, Bt, C and bias 16-byte aligned (the tiles move
+ * 16-byte row pieces); anything else returns -22. */
 int vsn_gemm(vsn_handle h, const float* dev_A, int lda, const float* dev_Bt, int ldb, float* dev_C, int ldc,
              const float* dev_bias, int M, int Nc, int K, int flags, void* stream);
 

@@ -1,9 +1,10 @@
-"""TEST INFRASTRUCTURE ONLY - builds oracle/_ref/: the REFERENCE's own ViSNet model, compiled.
+"""TEST INFRASTRUCTURE ONLY - builds oracle/_ref/: the REFERENCE's own ViSNet model and the caller of its seam, compiled.
 
 Recipe (run by `__graft_entry__.build()` wherever /root/reference exists, i.e. in the build container):
 every module of the reference's model package is byte-compiled FROM THE SOURCE WHERE IT LIES
 (`/root/reference/src/ViSNet/__init__.py`, `ViSNet/model/{__init__,visnet,visnet_block,utils,output_modules,
-priors}.py`) with CPython's own compiler into sourceless `oracle/_ref/ViSNet/**/<module>.pyc`.  No reference source
+priors}.py`, and the five caller-side files `AIMD/fragment.py`, `Calculators/{device_strategy,combiner,bonded}.py`,
+`utils/utils.py`) with CPython's own compiler into sourceless `oracle/_ref/ViSNet/**/<module>.pyc`.  No reference source
 enters the repository: `oracle/_ref/` is a build output like `libvsn_hip.so` - git-ignored, NOT gpurun-ignored, so it
 travels to the GPU box, where `/root/reference` does not exist.  There it is what `bench.py`'s `cpu_baseline` leg
 times (kind "reference": the reference's CPU path, not the oracle port) and what the smoke test may check against.
@@ -29,6 +30,12 @@ OUT = os.path.join(HERE, "_ref")
 PACKAGE = "ViSNet"
 
 
+# the caller side of the seam: loaded by oracle/ref_caller.py so that the
+# reference's OWN DLBondedCalculator drives the HIP seam on the GPU box (tests/test_gpu_reference_caller.py)
+CALLER_FILES = ("AIMD/fragment.py", "Calculators/device_strategy.py", "Calculators/combiner.py",
+                "Calculators/bonded.py", "utils/utils.py")
+
+
 def _modules():
     root = os.path.join(REF_SRC, PACKAGE)
     for d, _, files in os.walk(root):
@@ -37,6 +44,9 @@ def _modules():
         for f in sorted(files):
             if f.endswith(".py"):
                 yield os.path.relpath(os.path.join(d, f), REF_SRC)
+    for f in CALLER_FILES:
+        if os.path.exists(os.path.join(REF_SRC, f)):
+            yield f
 
 
 def build(force: bool = False) -> str | None:

@@ -1,0 +1,127 @@
+"""GPU: the REFERENCE's own caller drives the HIP seam.
+
+`Calculators/bonded.py` (DLBondedCalculator.__init__ / calculate / __call__, :25-123), `Calculators/combiner.py`,
+`Calculators/device_strategy.py`, `AIMD/fragment.py` and `utils/utils.py` of the reference are executed UNCHANGED - on
+the GPU box from `oracle/_ref` (the files byte-compiled by oracle/make_ref.py; `/root/reference` does not exist
+there), through oracle/ref_caller.py - with the two names north_star swaps:
+
+    Calculators.visnet_calculator.get_visnet_model  = ai2bmd_amd.visnet_calculator.get_visnet_model   (HIP seam)
+    Fragmentation.DistanceFragment                  = ai2bmd_amd.distancefrag.DistanceFragment        (HIP cap-H)
+
+Two `cuda:0` entries in `DeviceStrategy._bonded_devices` make the reference's ThreadPoolExecutor (bonded.py:75-77) run
+two model handles from two Python threads, and chunk size 120 atoms makes every handle see several FragmentData
+slices (`device_strategy.py:84-127`).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _protein(name):
+    from ai2bmd_amd.fragmentation import ProteinAtoms
+
+    d = np.load(os.path.join(GOLDEN, f"protein_{name}.npz"))
+    return ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+
+
+@pytest.fixture(scope="module")
+def ckpt_dir(lib_built, tmp_path_factory):
+    from ai2bmd_amd.synthetic import default_hparams, make_state_dict, write_lightning_ckpt
+
+    td = tmp_path_factory.mktemp("ckpt")
+    hp = default_hparams()
+    write_lightning_ckpt(str(td / "visnet-uni-bench.ckpt"), hp, make_state_dict(hp, seed=2024))
+    return str(td)
+
+
+def _reference_caller(relax=True):
+    from ai2bmd_amd.distancefrag import DistanceFragment
+    from ai2bmd_amd.visnet_calculator import get_visnet_model
+    from oracle.ref_caller import caller_source, load_reference_caller
+
+    assert caller_source() is not None, ("oracle/_ref (built by __graft_entry__.build() -> oracle/make_ref.py) must "
+                                         "travel with the snapshot: the reference's caller is not importable")
+    calls = []
+
+    def traced_get_visnet_model(model_path, device):
+        m = get_visnet_model(model_path, device)
+        inner = m.dl_potential_loader
+
+        def traced(frag_data):
+            import threading
+
+            calls.append((id(m), threading.get_ident(), len(frag_data), type(frag_data).__module__))
+            return inner(frag_data)
+
+        m.dl_potential_loader = traced
+        return m
+
+    class Fragmenter(DistanceFragment):  # (same class; only the constructor default differs for the "placed" run)
+        def __init__(self):
+            super().__init__(relax=relax)
+
+    ref = load_reference_caller(traced_get_visnet_model, Fragmenter)
+    DS = ref.DeviceStrategy
+    DS._gpu_count, DS._bonded_devices, DS._default_device, DS._chunk_size = 1, ["cuda:0", "cuda:0"], "cuda:0", 120
+    DS._optimiser_device = "cuda:0"
+    return ref, DS, calls
+
+
+@pytest.mark.parametrize("name", ["chig", "ww"])
+def test_reference_dl_bonded_calculator_on_the_hip_seam(ckpt_dir, name):
+    ref, DS, calls = _reference_caller()
+    assert ref.DLBondedCalculator.__module__ == "Calculators.bonded"
+    calc = ref.DLBondedCalculator(ckpt_dir, "bench")                  # the reference's own constructor
+    assert len(calc.models) == 2 and all(m.device == "cuda:0" for m in calc.models)
+    prot = _protein(name)
+    calc.fragment_method.fragment(prot)                               # simulator.py:53-57 initialize_fragcalc
+    DS.set_work_partitions(prot.fragments_start.tolist(), prot.fragments_end.tolist())
+    work = DS.get_work_partitions()
+    assert {w[0] for w in work} == {0, 1} and len(work) >= 4          # both handles, several chunks each
+    E, F = calc(prot)                                                 # the reference's own __call__
+    # the reference's executor ran the two handles on two worker threads, every chunk as the REFERENCE's FragmentData
+    assert len(calls) == len(work) and len({c[0] for c in calls}) == 2 and len({c[1] for c in calls}) == 2
+    assert {c[3] for c in calls} == {"AIMD.fragment"}
+    g = np.load(os.path.join(GOLDEN, f"visnet_prot_{name}.npz"))
+    Fg, Eg = g["Fprot64_relaxed"], float(g["Eprot64_relaxed"])
+    assert isinstance(F, np.ndarray) and F.shape == Fg.shape and F.dtype == np.float32
+    assert np.abs(F - Fg).max() <= 1e-4 * max(1.0, np.abs(Fg).max()), np.abs(F - Fg).max()
+    assert abs(float(E) - Eg) <= 1e-4 * max(1.0, abs(Eg))
+    # ... and equals the mirror class (ai2bmd_amd.bonded.DLBondedCalculator) on the same handles and partitions
+    from ai2bmd_amd.bonded import DLBondedCalculator as Mirror
+
+    mirror = Mirror.from_models(calc.models, chunk_atoms=120, fragment_method=calc.fragment_method)
+    Em, Fm = mirror(prot)
+    assert mirror._work == [tuple(w) for w in work]
+    np.testing.assert_allclose(F, Fm, rtol=0, atol=2e-6)
+    assert abs(float(E) - float(Em)) <= 2e-5 * max(1.0, abs(Eg))
+
+
+def test_reference_caller_against_the_all_reference_chain_golden(ckpt_dir):
+    """tests/golden/refchain_chig.npz (oracle/make_refchain_golden.py): fragmenter, model, split and combiner ALL the
+    reference's own code, cap hydrogens at their first-guess positions.  Here: the reference's DLBondedCalculator on
+    the HIP seam with the HIP fragment producer's relaxation switched off = the same geometry."""
+    ref, DS, calls = _reference_caller(relax=False)
+    calc = ref.DLBondedCalculator(ckpt_dir, "bench")
+    prot = _protein("chig")
+    calc.fragment_method.fragment(prot)
+    DS.set_work_partitions(prot.fragments_start.tolist(), prot.fragments_end.tolist())
+    E, F = calc(prot)
+    g = np.load(os.path.join(GOLDEN, "refchain_chig.npz"))
+    Fg, Eg = g["Fprot64"], float(g["Eprot64"])
+    assert np.abs(F - Fg).max() <= 1e-4 * max(1.0, np.abs(Fg).max()), np.abs(F - Fg).max()
+    assert np.abs(F - Fg).mean() <= 1e-5 * max(1.0, np.abs(Fg).mean())
+    assert abs(float(E) - Eg) <= 1e-4 * max(1.0, abs(Eg))
+    # no worse than 4x the reference's own fp32 error on this chain
+    ref_err = max(np.abs(g["Fprot32"] - Fg).max(), 2e-6)
+    assert np.abs(F - Fg).max() <= 4 * ref_err + 1e-6 * np.abs(Fg).max()
+    # the recombination indices our fragment producer leaves are what the reference's leaves: torch, default device
+    assert torch.is_tensor(prot.select_index) and prot.select_index.device.type == "cuda"
+    assert len(prot.select_index) == len(g["select_index"]) and len(prot.origin_index) == len(g["origin_index"])
+    assert np.array_equal(np.sort(prot.origin_index.cpu().numpy()), np.sort(g["origin_index"]))

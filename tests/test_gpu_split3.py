@@ -127,3 +127,26 @@ def test_fragment_batch_in_split3_mode(lib_built, fuse_panel):
     e0, f0 = m.dl_potential_loader(frag(z, pos, start, end))
     assert not np.array_equal(f0, f)  # the mode really took the other kernel
     np.testing.assert_allclose(f, f0, rtol=0, atol=2e-5)
+
+
+def test_reloading_weights_drops_the_split3_planes(lib_built):
+    """the packed bf16 planes are cached per weight ADDRESS; vsn_load_weight + vsn_finalize frees and
+    re-allocates the arena (very likely at the same addresses), so the cache must be dropped with it - a reload with
+    the mode on must give the NEW weights' forces, in split mode and back in fp32."""
+    hp = default_hparams(embedding_dimension=256, num_layers=2)
+    z, pos, start, end = random_fragments(31, [22, 12, 30, 19])
+    m = split3(model_for(hp, 7))
+    fd = frag(z, pos, start, end)
+    e_a, f_a = m.dl_potential_loader(fd)                       # planes of the seed-7 weights are cached now
+    sd_b = make_state_dict(hp, seed=8)
+    m.engine.load_state_dict(sd_b)
+    e_b, f_b = m.dl_potential_loader(fd)
+    E64, F64, _ = ViSNetOracle(hp, sd_b, torch.float64).energy_forces(z, pos, start, end)
+    check(e_b, f_b, E64, F64)
+    assert np.abs(f_b - f_a).max() > 1e-3                      # (really different weights)
+    fresh = split3(model_for(hp, 8))
+    e_c, f_c = fresh.dl_potential_loader(fd)
+    assert np.array_equal(f_b, f_c) and np.array_equal(e_b, e_c)
+    m.engine.set_option("gemm_split3", 0)
+    e_d, f_d = m.dl_potential_loader(fd)
+    check(e_d, f_d, E64, F64)

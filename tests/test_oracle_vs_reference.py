@@ -168,9 +168,11 @@ def test_live_reference_load_model_reads_our_checkpoint(tmp_path):
     np.testing.assert_allclose(F_ref.detach().numpy(), F, atol=2e-4)
 
 
-def test_reference_bonded_calculator_drives_our_seam_unchanged(lib_built):
-    """The reference's OWN Calculators/bonded.py (DLBondedCalculator.__init__/calculate/__call__, :25-123), loaded from
-    /root/reference with its absent imports stubbed, is pointed at a `get_visnet_model` that returns an object with our
+@pytest.mark.parametrize("origin", ["source", "compiled"])
+def test_reference_bonded_calculator_drives_our_seam_unchanged(lib_built, origin):
+    """The reference's OWN Calculators/bonded.py (DLBondedCalculator.__init__/calculate/__call__, :25-123), loaded
+    through oracle/ref_caller.py - from /root/reference ("source") and from the byte-compiled oracle/_ref the GPU box
+    uses ("compiled"; tests/test_gpu_reference_caller.py runs the same caller on the HIP seam) - is pointed at a `get_visnet_model` that returns an object with our
     seam's shape (`dl_potential_loader(FragmentData) -> (e[B,1], f[N,3])` numpy; here backed by the CPU oracle, the HIP
     model needs a GPU) and at a fragment producer handing out OUR FragmentData.  It runs unchanged and its result
     equals the mirror class's (ai2bmd_amd.bonded.DLBondedCalculator) on the same inputs."""
@@ -214,43 +216,12 @@ def test_reference_bonded_calculator_drives_our_seam_unchanged(lib_built):
             pos[ace] = pos[hplan.alias[ace]]
             return FragmentData(plan.z, pos, plan.start, plan.end, make_batch_index(plan.start, plan.end))
 
-    stubs = (("ase", {"Atoms": object}),)
-    ref_fragment = _load_reference_module("ref_fragment2", "AIMD/fragment.py", stubs=stubs)
-    ref_ds = _load_reference_module(
-        "ref_device_strategy2", "Calculators/device_strategy.py",
-        stubs=(("AIMD", {}), ("AIMD.fragment", {"FragmentInfo": object}), ("utils", {}),
-               ("utils.system", {"get_physical_core_count": lambda: 8})))
-    ref_comb = _load_reference_module("ref_combiner2", "Calculators/combiner.py")
-    saved = {k: sys.modules.get(k) for k in ("AIMD", "AIMD.arguments", "AIMD.fragment", "AIMD.protein",
-                                              "Calculators", "Calculators.combiner", "Calculators.device_strategy",
-                                              "Calculators.visnet_calculator", "Fragmentation", "utils", "utils.utils")}
-    try:
-        def mod(name, **attrs):
-            m = types.ModuleType(name)
-            for k, v in attrs.items():
-                setattr(m, k, v)
-            sys.modules[name] = m
-            return m
+    from oracle.ref_caller import load_reference_caller
 
-        mod("AIMD", arguments=mod("AIMD.arguments"))
-        mod("AIMD.fragment", FragmentData=ref_fragment.FragmentData)
-        mod("AIMD.protein", Protein=object)
-        mod("Calculators")
-        mod("Calculators.combiner", DipeptideBondedCombiner=ref_comb.DipeptideBondedCombiner)
-        mod("Calculators.device_strategy", DeviceStrategy=ref_ds.DeviceStrategy)
-        mod("Calculators.visnet_calculator", ViSNetModelLike=object,
-            get_visnet_model=lambda model_path, device: OracleSeam(device))
-        mod("Fragmentation", DistanceFragment=Fragmenter)
-        mod("utils")
-        mod("utils.utils", numpy_to_torch=lambda a, device=None: torch.as_tensor(np.asarray(a)))
-        ref_bonded = _load_reference_module("ref_bonded", "Calculators/bonded.py")
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                sys.modules.pop(k, None)
-            else:
-                sys.modules[k] = v
-    DS = ref_ds.DeviceStrategy
+    ref = load_reference_caller(lambda model_path, device: OracleSeam(device), Fragmenter, prefer=origin)
+    assert ref.origin == origin
+    ref_bonded = ref.bonded
+    DS = ref.DeviceStrategy
     DS._gpu_count, DS._bonded_devices, DS._default_device, DS._chunk_size = 0, ["cpu", "cpu"], "cpu", 120
     DS.set_work_partitions(plan.start.tolist(), plan.end.tolist())
     calc = ref_bonded.DLBondedCalculator("/ckpts", "test")            # the reference's own constructor

@@ -40,3 +40,21 @@ def test_protein_golden_is_consistent_with_the_plan(name):
         # forces do not - the cap hydrogens' rows are dropped by select_index, combiner.py:38)
         for a, b in zip(d["start"], d["end"]):
             assert np.abs(d[f"F_ref64_{tag}"][a:b].sum(0)).max() < 1e-9
+
+
+def test_builder_chain_golden_equals_the_all_reference_chain():
+    """tests/golden/refchain_chig.npz (oracle/make_refchain_golden.py) is produced by the reference's OWN fragmenter,
+    model, FragmentData split and DipeptideBondedCombiner - no builder arithmetic anywhere.  The protein goldens every
+    device-pipeline test uses (`Fprot64_placed` etc., oracle/make_protein_golden.py) recombine the reference model's
+    fragment forces with our combine_host on our plan: the two chains agree to fp64 round-off, which pins the latter."""
+    a = np.load(os.path.join(GOLDEN, "refchain_chig.npz"))
+    b = np.load(os.path.join(GOLDEN, "visnet_prot_chig.npz"))
+    assert int(a["weight_seed"]) == int(b["weight_seed"])
+    assert abs(float(a["Eprot64"]) - float(b["Eprot64_placed"])) < 1e-10
+    assert np.abs(a["Fprot64"] - b["Fprot64_placed"]).max() < 1e-12
+    # the reference's rows are in AMBER order, ours in residue order: same multiset of atoms per fragment
+    assert np.array_equal(a["start"], b["start"]) and np.array_equal(a["end"], b["end"])
+    for s, e in zip(a["start"], a["end"]):
+        assert sorted(a["z"][s:e].tolist()) == sorted(b["z"][s:e].tolist())
+    # the fp32 run of the same all-reference chain: the error floor the HIP path is compared with
+    assert np.abs(a["Fprot32"] - a["Fprot64"]).max() < 1e-5
