@@ -312,6 +312,22 @@ class ViSNetModel:
 
     def dl_potential_loader(self, frag_data: FragmentData):
         """-> (e float32 [B_nonempty, 1], f float32 [N, 3]) as numpy, like the reference (:54-63)."""
+        with self._call_lock():
+            return self._dl_potential_loader(frag_data)
+
+    def _call_lock(self):
+        """One handle = one device, one stream, one workspace and one set of staging buffers: concurrent callers of the
+        SAME handle serialise here.  The reference's factory hands the same model to every entry of
+        DeviceStrategy.get_bonded_devices() that names the same device (`_local_calc`, visnet_calculator.py:184-204) and
+        its DLBondedCalculator drives each entry from its own thread (bonded.py:75-77)."""
+        lock = self.__dict__.get("_lock")
+        if lock is None:
+            import threading
+
+            lock = self.__dict__.setdefault("_lock", threading.Lock())
+        return lock
+
+    def _dl_potential_loader(self, frag_data: FragmentData):
         z_host = np.ascontiguousarray(frag_data.z, dtype=np.int64)
         if z_host.size and (z_host.min() < 0 or z_host.max() >= self.engine.z_limit):
             # nn.Embedding / Atomref raise for an index outside their table (visnet_block.py:110, priors.py:86-87)

@@ -160,25 +160,29 @@ def test_plan_entry_points_reject_bad_arguments(lib_built):
     assert L.vsn_combine_with_energy(None, None, None, None, None) == -22
 
 
-def test_bench_self_launches_its_ranks_and_reports_one_line():
-    """`python bench.py --gpus 2` (no external launcher) must start two ranks itself, time with barrier +
-    max-over-ranks and print exactly one JSON line; --stub swaps the GPU step for a sleep on CPU over gloo."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_self_launches_its_ranks_and_reports_one_line(world):
+    """`python bench.py --gpus N` (no external launcher) must start N ranks itself, time with barrier +
+    max-over-ranks and print exactly one JSON line; --stub swaps the GPU step for a sleep on CPU over gloo.
+    N = 8 is the driver's scaling run (one rank per GPU of a node)."""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
-                        "--stub"], capture_output=True, text=True, timeout=300, env=env)
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "5",
+                        "--warmup", "1", "--stub"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["backend"] == "gloo"
+    assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["backend"] == "gloo"
     assert out["steps_requested"] == 5 and out["steps"] >= 5 and out["data"] == "STUB"
-    # rank 1 sleeps 4 ms per step, rank 0 only 2 ms: the reported time is the MAX over the ranks
-    assert out["ms_per_step"] >= 3.9
+    assert len(lines[0]) < 6000 and r.stdout.strip().splitlines()[-1] == lines[0]   # the result is the LAST stdout line
+    # rank k sleeps 2 (k + 1) ms per step: the reported time is the MAX over the ranks
+    assert out["ms_per_step"] >= 2.0 * world - 0.1
 
 
 def test_hparams_of_module_reads_scripted_activation_names():

@@ -70,8 +70,16 @@ from ai2bmd_amd.bonded import ShardedFragmentForces
 from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, fragment_positions, combine_host
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_ww.npz"))
-prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+which = sys.argv[2] if len(sys.argv) > 2 else "ww"
+if which == "mini5":  # ACE-TYR-TYR-ASP-NME cut out of Chignolin: 5 fragments, fewer than an 8-rank job has ranks
+    d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_chig.npz"))
+    m = (d["resnums"] <= 4) | (d["resnums"] == 12)
+    rn = d["resnums"][m].copy()
+    rn[rn == 12] = 5
+    prot = ProteinAtoms(d["names"][m], d["resnames"][m], rn, d["numbers"][m], d["positions"][m].astype(np.float64))
+else:
+    d = np.load(os.path.join(sys.argv[1], "tests", "golden", f"protein_{which}.npz"))
+    prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
 plan = build_plan(prot)
 ff = ShardedFragmentForces(plan, rank, world, "cpu")
 lo, hi = ff.atom_lo[rank], ff.atom_hi[rank]
@@ -109,8 +117,16 @@ from ai2bmd_amd.bonded import ShardedFragmentForces
 from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan, fragment_positions, combine_host
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
-d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_ww.npz"))
-prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+which = sys.argv[2] if len(sys.argv) > 2 else "ww"
+if which == "mini5":  # ACE-TYR-TYR-ASP-NME cut out of Chignolin: 5 fragments, fewer than an 8-rank job has ranks
+    d = np.load(os.path.join(sys.argv[1], "tests", "golden", "protein_chig.npz"))
+    m = (d["resnums"] <= 4) | (d["resnums"] == 12)
+    rn = d["resnums"][m].copy()
+    rn[rn == 12] = 5
+    prot = ProteinAtoms(d["names"][m], d["resnames"][m], rn, d["numbers"][m], d["positions"][m].astype(np.float64))
+else:
+    d = np.load(os.path.join(sys.argv[1], "tests", "golden", f"protein_{which}.npz"))
+    prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
 plan = build_plan(prot)
 
 def stub_force(pos):  # deterministic per-row function standing in for the network
@@ -167,15 +183,19 @@ for it in range(2):  # second call: the exchange buffers are reused
     E_ref, F_ref = combine_host(plan, e_ref[(plan.end - plan.start) > 0], stub_force(torch.as_tensor(full)).numpy())
     assert abs(float(E) - E_ref) < 1e-2 * max(1, abs(E_ref)), (float(E), E_ref)
     assert np.abs(F.numpy() - F_ref).max() < 1e-3, np.abs(F.numpy() - F_ref).max()
-assert eng.calls == 2
-# this rank's slot of the gathered buffer IS what the engine wrote through the views; the other rank's slot arrived
 lo, hi = ff.atom_lo[rank], ff.atom_hi[rank]
+# a rank that owns no fragment (fewer fragments than ranks) never calls the engine but DID enter both collectives
+assert eng.calls == (2 if hi > lo else 0) and (ff.f1 - ff.f0 > 0) == (hi > lo)
+# this rank's slot of the gathered buffer IS what the engine wrote through the views; every other rank's slot arrived
 mine = ff.recv[rank * ff.slot: rank * ff.slot + (hi - lo) * 3].view(-1, 3)
 assert torch.equal(mine, stub_force(ff.frag_pos[: hi - lo]))
-other = 1 - rank
-assert ff.recv[other * ff.slot: other * ff.slot + ff.rows[other] * 3].abs().sum() > 0
+for other in range(world):
+    if other != rank and ff.rows[other]:
+        assert ff.recv[other * ff.slot: other * ff.slot + ff.rows[other] * 3].abs().sum() > 0
+assert sum(ff.rows) == len(plan.z) and sum(ff.nfrag) == len(plan.start) and ff.slot % 3 == 0
+assert ff.slot >= 3 * max(ff.rows) + max(ff.nfrag)
 # without the relaxation a rank gathers only ITS rows of the fragment geometry
-assert ff.frag_pos.shape[0] == hi - lo
+assert ff.frag_pos.shape[0] == max(hi - lo, 1)
 print(f"rank {rank} for_engine ok rows={ff.local_rows} frags={ff.f1 - ff.f0} slot={ff.slot}")
 dist.destroy_process_group()
 '''
@@ -194,6 +214,59 @@ def test_for_engine_wiring_world2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 for_engine ok" in r.stdout and "rank 1 for_engine ok" in r.stdout
+
+
+@pytest.mark.parametrize("which,port", [("ww", 29547), ("mini5", 29549)])
+def test_for_engine_wiring_world8_gloo(tmp_path, which, port):
+    """The same product wiring at the size the driver's scaling run uses: EIGHT ranks - the WW domain (69 fragments:
+    8 or 9 per rank) and a 5-fragment peptide, where three ranks own NOTHING (`nloc == 0`: no engine call, zero-row
+    views into the exchange buffer, `max_rows` padding from the largest rank) and still enter the all-gather and
+    produce the same recombined forces."""
+    script = tmp_path / "worker_fe8.py"
+    script.write_text(WORKER_FOR_ENGINE)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), str(script), ROOT, which]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(8):
+        assert f"rank {k} for_engine ok" in r.stdout
+    if which == "mini5":
+        assert r.stdout.count("rows=0 frags=0") == 3
+
+
+def test_single_rank_never_enters_a_collective(monkeypatch):
+    """SCALE's N = 1 point must be BENCH's code path: with world == 1 the evaluator writes into the buffer the combine
+    reads and `torch.distributed` is never touched (it is not even initialised in bench.py's Ctx)."""
+    import torch
+    import torch.distributed as dist
+
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+    from ai2bmd_amd.fragmentation import build_plan
+
+    def boom(*a, **k):
+        raise AssertionError("collective entered at world == 1")
+
+    for name in ("all_gather_into_tensor", "all_gather", "all_reduce", "barrier", "broadcast"):
+        monkeypatch.setattr(dist, name, boom)
+    plan = build_plan(load_protein("chig"))
+    ff = ShardedFragmentForces(plan, rank=0, world=1, device="cpu")
+    assert ff.ranges == [(0, len(plan.start))] and ff.local_rows == len(plan.z)
+    n = len(plan.z)
+    ff.local_fn = lambda pos: (torch.arange(len(plan.start), dtype=torch.float32), torch.ones(n, 3))
+    ff.combine_fn = lambda buf: buf[: n * 3].view(-1, 3).clone()
+    E, F = ff.step(torch.zeros(plan.n_prot, 3))
+    assert F.shape == (n, 3) and float(F.sum()) == 3 * n and torch.isfinite(E)
+    # bench.py: a single process builds no process group at all
+    import bench
+
+    a = bench.parse_args(["--stub"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("RANK", raising=False)
+    ctx = bench.Ctx(a)
+    assert ctx.world == 1 and ctx.backend is None and not dist.is_initialized()
+    ctx.barrier()
+    assert ctx.max_over_ranks(1.5) == 1.5
 
 
 def test_sharded_path_world2_gloo(tmp_path, lib_built):

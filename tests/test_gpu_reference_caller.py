@@ -40,27 +40,32 @@ def ckpt_dir(lib_built, tmp_path_factory):
     return str(td)
 
 
-def _reference_caller(relax=True):
+def _reference_caller(relax=True, handles="shared"):
+    """handles: "shared" = the factory as it is - like the reference's `_local_calc` it hands ONE model to both
+    'cuda:0' entries, so the reference's two executor threads call the same handle concurrently (serialised inside the
+    seam); "separate" = one handle per entry (what two different devices give)."""
+    import threading
+
     from ai2bmd_amd.distancefrag import DistanceFragment
-    from ai2bmd_amd.visnet_calculator import get_visnet_model
+    from ai2bmd_amd.visnet_calculator import ViSNetModel, get_visnet_model
     from oracle.ref_caller import caller_source, load_reference_caller
 
     assert caller_source() is not None, ("oracle/_ref (built by __graft_entry__.build() -> oracle/make_ref.py) must "
                                          "travel with the snapshot: the reference's caller is not importable")
     calls = []
 
+    class Traced:  # forwards everything; records who called the seam with what
+        def __init__(self, inner):
+            self.inner, self.device = inner, inner.device
+
+        def dl_potential_loader(self, frag_data):
+            calls.append((id(self), threading.get_ident(), len(frag_data), type(frag_data).__module__))
+            return self.inner.dl_potential_loader(frag_data)
+
     def traced_get_visnet_model(model_path, device):
-        m = get_visnet_model(model_path, device)
-        inner = m.dl_potential_loader
-
-        def traced(frag_data):
-            import threading
-
-            calls.append((id(m), threading.get_ident(), len(frag_data), type(frag_data).__module__))
-            return inner(frag_data)
-
-        m.dl_potential_loader = traced
-        return m
+        m = get_visnet_model(model_path, device) if handles == "shared" else ViSNetModel.from_file(
+            model_path=model_path, device=device)
+        return Traced(m)
 
     class Fragmenter(DistanceFragment):  # (same class; only the constructor default differs for the "placed" run)
         def __init__(self):
@@ -73,21 +78,24 @@ def _reference_caller(relax=True):
     return ref, DS, calls
 
 
-@pytest.mark.parametrize("name", ["chig", "ww"])
-def test_reference_dl_bonded_calculator_on_the_hip_seam(ckpt_dir, name):
-    ref, DS, calls = _reference_caller()
+@pytest.mark.parametrize("name,handles", [("chig", "shared"), ("chig", "separate"), ("ww", "separate")])
+def test_reference_dl_bonded_calculator_on_the_hip_seam(ckpt_dir, name, handles):
+    ref, DS, calls = _reference_caller(handles=handles)
     assert ref.DLBondedCalculator.__module__ == "Calculators.bonded"
     calc = ref.DLBondedCalculator(ckpt_dir, "bench")                  # the reference's own constructor
     assert len(calc.models) == 2 and all(m.device == "cuda:0" for m in calc.models)
+    assert (calc.models[0].inner is calc.models[1].inner) == (handles == "shared")
     prot = _protein(name)
     calc.fragment_method.fragment(prot)                               # simulator.py:53-57 initialize_fragcalc
     DS.set_work_partitions(prot.fragments_start.tolist(), prot.fragments_end.tolist())
     work = DS.get_work_partitions()
     assert {w[0] for w in work} == {0, 1} and len(work) >= 4          # both handles, several chunks each
     E, F = calc(prot)                                                 # the reference's own __call__
-    # the reference's executor ran the two handles on two worker threads, every chunk as the REFERENCE's FragmentData
+    # the reference's executor ran the two entries on two worker threads, one call per chunk; every chunk is a slice
+    # (`fragments[start:end]`, bonded.py:73) of the FragmentData our fragment producer handed out
     assert len(calls) == len(work) and len({c[0] for c in calls}) == 2 and len({c[1] for c in calls}) == 2
-    assert {c[3] for c in calls} == {"AIMD.fragment"}
+    assert {c[3] for c in calls} == {"ai2bmd_amd.fragment"}
+    assert sorted(c[2] for c in calls) == sorted(w[2] - w[1] for w in work)
     g = np.load(os.path.join(GOLDEN, f"visnet_prot_{name}.npz"))
     Fg, Eg = g["Fprot64_relaxed"], float(g["Eprot64_relaxed"])
     assert isinstance(F, np.ndarray) and F.shape == Fg.shape and F.dtype == np.float32
@@ -96,7 +104,7 @@ def test_reference_dl_bonded_calculator_on_the_hip_seam(ckpt_dir, name):
     # ... and equals the mirror class (ai2bmd_amd.bonded.DLBondedCalculator) on the same handles and partitions
     from ai2bmd_amd.bonded import DLBondedCalculator as Mirror
 
-    mirror = Mirror.from_models(calc.models, chunk_atoms=120, fragment_method=calc.fragment_method)
+    mirror = Mirror.from_models([m.inner for m in calc.models], chunk_atoms=120, fragment_method=calc.fragment_method)
     Em, Fm = mirror(prot)
     assert mirror._work == [tuple(w) for w in work]
     np.testing.assert_allclose(F, Fm, rtol=0, atol=2e-6)
