@@ -88,6 +88,8 @@ def lib() -> C.CDLL:
     L.vsn_profile_read.restype = C.c_int
     L.vsn_profile_read_scatter.argtypes = [vp, C.POINTER(C.c_double)]
     L.vsn_profile_read_scatter.restype = C.c_int
+    L.vsn_profile_read_walks.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    L.vsn_profile_read_walks.restype = C.c_int
     L.vsn_profile_bracket_ms.argtypes = [vp]
     L.vsn_profile_bracket_ms.restype = C.c_double
     L.vsn_last_num_edges.argtypes = [vp]
@@ -164,7 +166,7 @@ def i64_ptr(a):
 
 EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
-    "vsn_forces", "vsn_profile_read", "vsn_profile_read_scatter", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
+    "vsn_forces", "vsn_profile_read", "vsn_profile_read_scatter", "vsn_profile_read_walks", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_combine_plan_set_energy", "vsn_combine_with_energy", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
     "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_half1_build", "vsn_md_combine_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
     "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",

@@ -84,11 +84,14 @@ struct vsn_ctx {
   double prof[4][4] = {{0}};  // per GEMM kernel (128x128, 64x64, 128x32, grouped 64x64): launches, ms, flops, bytes
   // profile mode, scatter path: brackets around the forward edge-attention (0) and node-update (1) launches:
   // {launches, ms, algorithmic bytes, 0}
-  double sprof[2][4] = {{0}};
+  // (+ round 5) the reverse node walks of single-protein sizes: k_bwd_hf1 (2), k_bwd_hf2 (3), k_bwd_attn_S (4),
+  // k_bwd_norm_update (5)
+  static constexpr int NWALK = 6;
+  double sprof[NWALK][4] = {{0}};
   struct SRec {
     hipEvent_t a, b;
     int kind, N;
-    bool with_update, fused_norm;
+    int f0, f1;  // kind 0: with_update; 1: fused_norm; 2: with_eu; 3: K-slices of g_m, of g_A; 5: accumulate
   };
   std::vector<SRec> srecs;
   double prof_empty_ms = 0;   // profile mode: total time of EMPTY event brackets (the cost an event pair adds) ...
@@ -745,24 +748,20 @@ static void snapshot(vsn_ctx* c, hipStream_t st, const char* name, int layer, co
 struct ScatterBracket {
   vsn_ctx* c;
   bool on;
-  LaunchEvents ev{};
-  ScatterBracket(vsn_ctx* c_, hipStream_t, int kind, int N, bool with_update, bool fused_norm)
-      : c(c_), on(c_->profile) {
+  ScatterBracket(vsn_ctx* c_, hipStream_t, int kind, int N, int f0, int f1) : c(c_), on(c_->profile) {
     if (!on) return;
     vsn_ctx::SRec r;
     r.kind = kind;
     r.N = N;
-    r.with_update = with_update;
-    r.fused_norm = fused_norm;
+    r.f0 = f0;
+    r.f1 = f1;
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
-    ev.a = r.a;
-    ev.b = r.b;
     c->srecs.push_back(r);
-    set_launch_events(&ev);
+    push_launch_events(LaunchEvents{r.a, r.b});  // FIFO: taken by the next timed-capable launch of this thread
   }
   ~ScatterBracket() {
-    if (on) set_launch_events(nullptr);  // (the launch consumed it; a launch that was skipped must not leak it on)
+    if (on) set_launch_events(nullptr);  // (a launch that was skipped must not leak its pair to a later one)
   }
 };
 
@@ -939,7 +938,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     // single-protein sizes: the edge update rides in the attention launch (horizontal fusion)
     const bool fused_eu = c->fuse_fwd && !side_eu && !c->debug && !last && !l0 && N < 4096;
     {
-      ScatterBracket sb(c, st, 0, N, fused_eu, false);
+      ScatterBracket sb(c, st, 0, N, fused_eu ? 1 : 0, 0);
       if (fused_eu) RC(launch_edge_attn_update(st, D, b.qkv, b.pe, c->m, c->A, b.vp, c->f));
       else RC(launch_edge_attn(st, D, b.qkv, b.pe, c->m, c->A));
     }
@@ -963,7 +962,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
           nn = NextNorm{c->on_g, c->on_b, c->vo_w, c->xn_o, c->rstd_o, c->hb.cat0, c->vo, 2 * H};
         }
       }
-      ScatterBracket sb(c, st, 1, N, false, fuse_norm);
+      ScatterBracket sb(c, st, 1, N, fuse_norm ? 1 : 0, 0);
       RC(launch_node_update(st, D, b.tpre, b.vh, b.vp, b.o, c->x, c->vec, nn));
     }
     if (side_eu) HIPCHK(c, hipStreamWaitEvent(st, c->ev_join, 0));
@@ -983,6 +982,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
   RC(launch_head_backward(st, D, c->hw, c->hb, c->g_vo));
   const bool fuse_bwd = c->fuse_bwd_opt && c->hp.vecnorm_type == 0 && !c->debug;
   if (fuse_bwd) {
+    ScatterBracket sb(c, st, 5, N, 0, 0);
     RC(launch_bwd_norm_update(st, D, c->hb.g_cat0, 2 * H, c->g_vo, c->xn_o, c->rstd_o, c->on_g, c->vo_w, 0, c->g_x,
                               c->g_vec, c->lb[L - 1].vp, c->lb[L - 1].o, c->g_o, c->g_vp));
   } else {
@@ -1045,6 +1045,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       RC(launch_gemm_group(st, gd, ng));
     } else {
     if (streamless) {
+      ScatterBracket sb(c, st, 2, N, last ? 0 : 1, 0);
       RC(launch_bwd_hf1(st, D, c->g_vec, b.vh, b.tpre, c->g_t, c->g_geo, b.vp, b.pe, c->g_f, c->g_pe, c->g_vp, c->g_vh,
                         !last));
     } else if (side_bw) {
@@ -1081,11 +1082,15 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
       }
       RC(launch_gemm_group(st, gdr, 2));
     }
-    if (streamless && !last)
+    if (streamless && !last) {
+      ScatterBracket sb2(c, st, 3, N, mparts.n, aparts.n);  // (FIFO: the k_bwd_hf2 launch takes this pair ...
+      ScatterBracket sb4(c, st, 4, N, 0, 0);                //  ... and the k_bwd_attn_S launch behind it this one)
       RC(launch_bwd_hf2(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts, b.vp,
                         c->g_f, c->g_vp));
-    else
+    } else {
+      ScatterBracket sb4(c, st, 4, N, 0, 0);  // (k_bwd_attn_T is not a timed launch: the pair goes to k_bwd_attn_S)
       RC(launch_bwd_attn(st, D, b.qkv, b.pe, c->g_A, c->g_m, c->g_pe, c->g_qkv, c->sat_tmp, c->g_geo, mparts, aparts));
+    }
     snapshot(c, st, "g_m", l, c->g_m, (size_t)Emax * H);
     snapshot(c, st, "g_pe", l, c->g_pe, (size_t)Emax * 3 * H);
     snapshot(c, st, "g_qkv", l, c->g_qkv, (size_t)N * 3 * H);
@@ -1106,10 +1111,11 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
     }
     snapshot(c, st, "g_vh", l, c->g_vh, (size_t)N * S * H);
     snapshot(c, st, "g_xh", l, c->g_xh, (size_t)N * H);
-    if (fuse_bwd && l > 0)  // norm adjoint of this layer + node-update adjoint of the layer below, one pass
+    if (fuse_bwd && l > 0) {  // norm adjoint of this layer + node-update adjoint of the layer below, one pass
+      ScatterBracket sb(c, st, 5, N, 1, 0);
       RC(launch_bwd_norm_update(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w, 1, c->g_x, c->g_vec,
                                 c->lb[l - 1].vp, c->lb[l - 1].o, c->g_o, c->g_vp));
-    else if (!(fuse_bwd && l0))  // (fused reverse pass: layer 0's LayerNorm adjoint rides in the edge-embedding adjoint)
+    } else if (!(fuse_bwd && l0))  // (fused reverse pass: layer 0's LayerNorm adjoint rides in the edge-embedding adjoint)
       RC(launch_bwd_node_norm(st, D, c->g_xh, H, c->g_vh, b.xn, b.rstd, w.ln_g, w.vln_w,
                               l0 ? 3 /* skip the vec part */ : c->hp.vecnorm_type, 1, c->g_x, c->g_vec));
     // layer 0 normalises vec == 0, which does not depend on the positions: nothing to propagate
@@ -1229,13 +1235,37 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
         if (!timed) continue;
-        const double H = c->H, S = c->S, n = r.N, e = E;
-        double fl;
-        if (r.kind == 0)  // edge attention (+ edge update): pe[dk|dv], C, src | qkv | m, A  (+ pe[f], f r/w, d, vp[wt|ws])
-          fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1) + (r.with_update ? e * (3 * H + 8) + n * S * 2 * H : 0.0);
-        else  // node update: tpre, d, src | vh, vp[vec1..3], o, x r/w, vec r/w (+ next layer's xn, xh, rstd, vh)
-          fl = e * (2 * H + 8 + 1) + n * (S * H * (1 + 3 + 2) + 3 * H + 2 * H + 1) +
-               (r.fused_norm ? n * (2 * H + 1 + S * H) : 0.0);
+        const double H = c->H, S = c->S, n = r.N, e = E, nh = c->nh;
+        double fl;  // floats: every distinct array the launch reads or writes, once (4-byte indices counted as floats)
+        switch (r.kind) {
+          case 0:  // edge attention (+ edge update): pe[dk|dv], C, src | qkv | m, A  (+ pe[f], f r/w, d, vp[wt|ws])
+            fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1) + (r.f0 ? e * (3 * H + 8) + n * S * 2 * H : 0.0);
+            break;
+          case 1:  // node update: tpre, d, src | vh, vp[vec1..3], o, x r/w, vec r/w (+ next layer's xn, xh, rstd, vh)
+            fl = e * (2 * H + 8 + 1) + n * (S * H * (1 + 3 + 2) + 3 * H + 2 * H + 1) +
+                 (r.f0 ? n * (2 * H + 1 + S * H) : 0.0);
+            break;
+          case 2:  // k_bwd_hf1 = vector messages (both sides) [+ edge update: per-edge half, source side]
+            // read tpre[2H], d, src|tgt|perm, g_geo[0..S) r/w | vh, g_vec; write g_t[2H] | g_vh
+            fl = e * (2 * H + 8 + 3 + 2 * S + 2 * H) + n * (3 * S * H + 2);
+            // + read pe[f], g_f, g_geo[16..16+S) r/w | vp[wt|ws]; write g_pe[f] | g_vp[ws]
+            if (r.f0) fl += e * (2 * H + 2 * S + H) + n * (3 * S * H);
+            break;
+          case 3:  // k_bwd_hf2 = attention target side + edge update per-node half
+            // read pe[dk|dv], the K-slices of g_m, C, g_geo[8] r/w, src | qkv, the K-slices of g_A;
+            // write g_m, g_pe[dk|dv], sat_tmp | g_q   + read pe[f], g_f, d | vp[ws]; write g_vp[wt]
+            fl = e * (2 * H + std::max(r.f0, 1) * H + 1 + 2 + 1 + H + 2 * H + 2 * nh) +
+                 n * (3 * H + std::max(r.f1, 1) * H + H + 2) + e * (2 * H + 8) + n * (2 * S * H);
+            break;
+          case 4:  // k_bwd_attn_S: read pe[dk|dv], g_m, sat_tmp, perm|tgt | q; write g_k, g_v
+            fl = e * (3 * H + 2 * nh + 2) + n * (3 * H + 1);
+            break;
+          default:  // 5, k_bwd_norm_update: read g_xh, xn, rstd, o[2H], g_vh, vp[3H] (+ g_x, g_vec when accumulating);
+                    // write g_x, g_vec, g_vp[3H], g_o[3H]
+            fl = n * (2 * H + 1 + 2 * H + S * H + 3 * S * H + H + S * H + 3 * S * H + 3 * H) +
+                 (r.f0 ? n * (H + S * H) : 0.0);
+            break;
+        }
         c->sprof[r.kind][0] += 1;
         c->sprof[r.kind][1] += ms;
         c->sprof[r.kind][2] += 4.0 * fl;
@@ -1280,6 +1310,14 @@ extern "C" int vsn_profile_read_scatter(vsn_handle c, double* out8) {
   for (int v = 0; v < 2; ++v)
     for (int k = 0; k < 4; ++k) out8[v * 4 + k] = c->sprof[v][k];
   return 0;
+}
+
+extern "C" int vsn_profile_read_walks(vsn_handle c, double* out, int max_kinds) {
+  if (!c || !out || max_kinds < 0) return -22;
+  const int n = std::min(max_kinds, (int)vsn_ctx::NWALK);
+  for (int v = 0; v < n; ++v)
+    for (int k = 0; k < 4; ++k) out[v * 4 + k] = c->sprof[v][k];
+  return n;
 }
 
 extern "C" double vsn_profile_bracket_ms(vsn_handle c) {

@@ -2,6 +2,7 @@
 // translation units.  All pointers are device pointers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <vector>
@@ -118,7 +119,21 @@ void set_gemm_profiler(GemmProfiler* p);  // thread-local; nullptr disables
 struct LaunchEvents {
   hipEvent_t a, b;
 };
-void set_launch_events(const LaunchEvents* ev);  // thread-local; consumed by that launch
+// thread-local FIFO (layer_fwd.hip): every launch that goes through launch_maybe_timed takes the front pair, if any.
+// Timed-capable launches: k_edge_attn[_update], k_node_update (forward); k_bwd_hf1, k_bwd_hf2, k_bwd_attn_S,
+// k_bwd_norm_update (reverse walks).  set_launch_events(nullptr) empties the queue.
+void set_launch_events(const LaunchEvents* ev);  // nullptr: clear; else: clear + push one
+void push_launch_events(const LaunchEvents& ev);
+bool take_launch_events(LaunchEvents* out);
+template <typename... KA, typename... A>
+static inline void launch_maybe_timed(void (*kern)(KA...), dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
+  LaunchEvents ev;
+  if (take_launch_events(&ev)) {
+    hipExtLaunchKernelGGL<KA...>(kern, g, b, lds, st, ev.a, ev.b, 0, static_cast<KA>(a)...);
+  } else {
+    hipLaunchKernelGGL(kern, g, b, lds, st, static_cast<KA>(a)...);
+  }
+}
 void set_gemm_splitk_workspace(float* p, size_t elems);  // thread-local scratch for split-K partials
 // opt-in product mode gemm_split3 (gemm_s3.h): the grouped launches of this thread run their members as 3 x bf16 split
 // products while a table is set; the table caches the packed weight planes of one engine

@@ -85,10 +85,12 @@ namespace vsn {
 
 int g_fuse_side = 2;  // single-protein sizes, reverse pass (env VSN_FUSE_SIDE): 2 = no second stream, the side kernels ride in
                       // main-chain launches (k_bwd_hf1/2); 1 = one fused side-stream launch per layer; 0 = three
+int g_part_layout = 2;  // k_bwd_hf1 / k_bwd_hf2: how their parts map onto workgroups (see part_of_block; env VSN_PART_LAYOUT)
 int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
 static const bool g_bwd_env_read = [] {  // A/B switches, read once when the library is loaded
   if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
   if (const char* e = getenv("VSN_FUSE_SIDE")) g_fuse_side = atoi(e);
+  if (const char* e = getenv("VSN_PART_LAYOUT")) g_part_layout = atoi(e);
   return true;
 }();
 // small batches (one protein per MD step): several waves per node
@@ -635,23 +637,46 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
 #ifndef VSN_HF1_MINWAVES
 #define VSN_HF1_MINWAVES 4
 #endif
+// Which part a workgroup runs and which node block it is (g_part_layout, env VSN_PART_LAYOUT):
+//   0  parts one after the other, G = gridDim / P blocks each: [0,G) part 0, [G,2G) part 1, ...  With G = N not a
+//      multiple of 8 the parts start on different XCDs (the dispatcher places workgroup b on XCD b % 8), so the
+//      xcd_block() slab of a node - and with it the fragment's rows, the per-edge streams and the neighbour rows all
+//      four parts read - is pulled into up to four different L2s: measured 67.7 MB fetched per k_bwd_hf1 launch
+//      against 41 MB of distinct arrays (profiles/r04_chig_md_pmc.csv).
+//   1  the same order with G rounded up to a multiple of 8 (blocks past N idle): every part of a node on ONE XCD.
+//   2  interleaved: workgroups 8 (P k + part) + xcd, i.e. the P parts of the k-th node of every XCD slab are
+//      dispatched back to back on that XCD - what one part pulled into the L2 is still there for the others.
+template <int P>
+__device__ __forceinline__ void part_of_block(int il, int& part, int& bid, int& G) {
+  const int b = (int)blockIdx.x;
+  G = (int)gridDim.x / P;
+  if (il) {
+    const int t = b >> 3;
+    part = t % P;
+    bid = ((t / P) << 3) + (b & 7);
+  } else {
+    part = b / G;
+    bid = b - part * G;
+  }
+}
 template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN), ((WPN > 1 && V <= 4 && !GEN) ? VSN_HF1_MINWAVES : 1)) void k_bwd_hf1(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
     float* __restrict__ g_t, float* __restrict__ g_geo, const float* __restrict__ vp, const float* __restrict__ pe,
     const float* __restrict__ g_f, float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_vh,
-    int with_eu) {
+    int with_eu, int il) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int G = (int)gridDim.x / (with_eu ? 4 : 2);
-  const int b = (int)blockIdx.x;
-  if (b < G) {
+  int part, b, G;
+  if (with_eu) part_of_block<4>(il, part, b, G);
+  else part_of_block<2>(il, part, b, G);
+  if (part == 0) {
     bwd_vecmsg_T_body<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, b, G);
-  } else if (!with_eu || b >= 3 * G) {
-    bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, b - (with_eu ? 3 * G : G), G);
-  } else if (b < 2 * G) {
-    bwd_edge_update_T_body<V, S, WPN, GEN, 1, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b - G, G);
+  } else if (!with_eu || part == 3) {
+    bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, b, G);
+  } else if (part == 1) {
+    bwd_edge_update_T_body<V, S, WPN, GEN, 1, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b, G);
   } else {
-    bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, b - 2 * G, G);
+    bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, b, G);
   }
 }
 template <int V, int S, int WPN, bool GEN>
@@ -659,12 +684,12 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf2(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
     float* __restrict__ g_geo, Parts mp, Parts ap, const float* __restrict__ vp, const float* __restrict__ g_f,
-    float* __restrict__ g_vp) {
+    float* __restrict__ g_vp, int il) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int G = (int)gridDim.x >> 1;
-  const int b = (int)blockIdx.x;
-  if (b < G) bwd_attn_T_body<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, b, G);
-  else bwd_edge_update_T_body<V, S, WPN, GEN, 1, 2>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b - G, G);
+  int part, b, G;
+  part_of_block<2>(il, part, b, G);
+  if (part == 0) bwd_attn_T_body<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, b, G);
+  else bwd_edge_update_T_body<V, S, WPN, GEN, 1, 2>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b, G);
 }
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
@@ -1159,15 +1184,41 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
 // the streamless reverse chain of a layer at single-protein sizes (see k_bwd_hf1 / k_bwd_hf2); false = not applicable
 bool bwd_streamless_ok(const Dims& D) { return g_fuse_side >= 2 && pick_wpn(D.N) != 1 && D.N > 0; }
 bool bwd_batch_path(const Dims& D) { return pick_wpn(D.N) == 1 && D.N > 0; }
+// (launch_maybe_timed: in profile mode these launches carry an event pair on their dispatch packet, kernels.h)
+#define VSN_KL4(NAME)                                                                      \
+  template <int V, int S, int W, bool G>                                                   \
+  struct KL_##NAME {                                                                       \
+    template <typename... A>                                                               \
+    static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {                 \
+      launch_maybe_timed(NAME<V, S, W, G>, g, b, lds, st, a...);                           \
+    }                                                                                      \
+  }
+VSN_KL4(k_bwd_hf1);
+VSN_KL4(k_bwd_hf2);
+VSN_KL4(k_bwd_attn_S);
+#undef VSN_KL4
+template <int V, int S, int W>
+struct KL_k_bwd_norm_update {
+  template <typename... A>
+  static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
+    launch_maybe_timed(k_bwd_norm_update<V, S, W>, g, b, lds, st, a...);
+  }
+};
+// blocks per part of the multi-part launches: one per node, rounded up to whole XCD rounds unless layout 0
+static inline int part_grid(int N, int w) {
+  const int g = node_grid(N, w);
+  return g_part_layout ? (g + 7) & ~7 : g;
+}
 int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre, float* g_t,
                    float* g_geo, const float* vp, const float* pe, const float* g_f, float* g_pe, float* g_vp,
                    float* g_vh, bool with_edge_update) {
   const int w = pick_wpn(D.N);
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   const int with_eu = with_edge_update ? 1 : 0;
-  VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf1,
-                   <<<(with_eu ? 4 : 2) * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
-                       D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu));
+  const int il = g_part_layout == 2 ? 1 : 0;
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_hf1,
+                   ::go((with_eu ? 4 : 2) * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
+                        D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu, il));
   return 0;
 }
 int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
@@ -1175,10 +1226,12 @@ int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float*
                    const float* vp, const float* g_f, float* g_vp) {
   const int w = pick_wpn(D.N);
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
-  VSN_DISPATCH_VSA(D.H, D.S, w, g__, k_bwd_hf2,
-                   <<<2 * node_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st>>>(
-                       D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp));
-  VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
+  const int il = g_part_layout == 2 ? 1 : 0;
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_hf2,
+                   ::go(2 * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
+                        D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp, il));
+  VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_attn_S,
+                   ::go(node_grid(D.N, w), node_block(w), node_lds(w, 2, D.H / 64), st, D, qkv, pe, g_m, sat_tmp, g_qkv));
   return 0;
 }
 // edge-update adjoint (both sides) + source side of the vector messages; one launch at single-protein sizes
@@ -1214,7 +1267,12 @@ int launch_bwd_attn(hipStream_t st, const Dims& D, const float* qkv, const float
                     float* g_pe, float* g_qkv, float* sat_tmp, float* g_geo, Parts g_m_parts, Parts g_A_parts) {
   if (D.N <= 0) return 0;
   VSN_LAUNCH_ACT(k_bwd_attn_T, 1, D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts);
-  VSN_LAUNCH_ACT(k_bwd_attn_S, 2, D, qkv, pe, g_m, sat_tmp, g_qkv);
+  {
+    const int w = pick_wpn(D.N);
+    const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
+    VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_attn_S,
+                     ::go(node_grid(D.N, w), node_block(w), node_lds(w, 2, D.H / 64), st, D, qkv, pe, g_m, sat_tmp, g_qkv));
+  }
   return 0;
 }
 // source side (dE/dk, dE/dv) + target side dE/dq, after fused.hip::k_bwd_gf_fused
@@ -1240,9 +1298,9 @@ int launch_bwd_norm_update(hipStream_t st, const Dims& D, const float* g_xh, int
                            float* g_vp) {
   if (D.N <= 0) return 0;
   const int w__ = pick_wpn(D.N);
-  VSN_DISPATCH_VS(D.H, D.S, w__, k_bwd_norm_update,
-                  <<<node_grid(D.N, w__), node_block(w__), w__ == 1 ? 0 : (size_t)(w__ - 1) * 2 * D.H * 4, st>>>(
-                      D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x, g_vec, vp, o, g_o, g_vp));
+  VSN_DISPATCH_VS(D.H, D.S, w__, KL_k_bwd_norm_update,
+                  ::go(node_grid(D.N, w__), node_block(w__), w__ == 1 ? 0 : (unsigned)((w__ - 1) * 2 * D.H * 4), st,
+                       D, g_xh, ldg, g_vh, xn, rstd, gamma, wvec, accumulate, g_x, g_vec, vp, o, g_o, g_vp));
   return 0;
 }
 int launch_bwd_embed_edge(hipStream_t st, const Dims& D, const float* x, const float* pp, const float* g_f,

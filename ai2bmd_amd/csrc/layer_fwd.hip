@@ -548,17 +548,20 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(
 // Profile mode (engine.hip, ScatterBracket): the scatter-path launches carry a pair of events ON THEIR DISPATCH
 // PACKET (hipExtLaunchKernelGGL).  The elapsed time between the two is the kernel's own begin / end timestamp - the
 // pair rocprofv3's kernel trace records - not a stream bracket whose marker packets add a size-dependent gap.
-static thread_local const LaunchEvents* tl_launch_ev = nullptr;
-void set_launch_events(const LaunchEvents* ev) { tl_launch_ev = ev; }
-template <typename... KA, typename... A>
-static inline void launch_maybe_timed(void (*kern)(KA...), dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
-  if (tl_launch_ev) {
-    const LaunchEvents ev = *tl_launch_ev;
-    tl_launch_ev = nullptr;
-    hipExtLaunchKernelGGL<KA...>(kern, g, b, lds, st, ev.a, ev.b, 0, static_cast<KA>(a)...);
-  } else {
-    hipLaunchKernelGGL(kern, g, b, lds, st, static_cast<KA>(a)...);
-  }
+static thread_local LaunchEvents tl_ev_q[8];
+static thread_local int tl_ev_n = 0, tl_ev_head = 0;
+void set_launch_events(const LaunchEvents* ev) {
+  tl_ev_n = tl_ev_head = 0;
+  if (ev) tl_ev_q[tl_ev_n++] = *ev;
+}
+void push_launch_events(const LaunchEvents& ev) {
+  if (tl_ev_head == tl_ev_n) tl_ev_n = tl_ev_head = 0;
+  if (tl_ev_n < 8) tl_ev_q[tl_ev_n++] = ev;
+}
+bool take_launch_events(LaunchEvents* out) {
+  if (tl_ev_head >= tl_ev_n) return false;
+  *out = tl_ev_q[tl_ev_head++];
+  return true;
 }
 #define VSN_KL(NAME)                                                                       \
   template <int V, int S, int W, bool G>                                                   \

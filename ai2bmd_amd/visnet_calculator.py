@@ -126,6 +126,17 @@ class ViSNetEngine:
         names = ("k_edge_attn", "k_node_update")
         return {names[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], bytes=out[4 * v + 2]) for v in range(2)}
 
+    WALKS = ("k_edge_attn", "k_node_update", "k_bwd_hf1", "k_bwd_hf2", "k_bwd_attn_S", "k_bwd_norm_update")
+
+    def profile_read_walks(self):
+        """-> {kernel: dict(launches, ms, bytes)} of every timed node walk (forward scatter path + the reverse walks of
+        single-protein sizes), accumulated since set_option('profile', 1); dispatch begin..end timestamps."""
+        out = (C.c_double * (4 * len(self.WALKS)))()
+        n = self._L.vsn_profile_read_walks(self._h, out, len(self.WALKS))
+        if n < 0:
+            self._check(n)
+        return {self.WALKS[v]: dict(launches=out[4 * v], ms=out[4 * v + 1], bytes=out[4 * v + 2]) for v in range(n)}
+
     def profile_bracket_ms(self) -> float:
         """Average cost of an empty HIP-event bracket measured in the profiled calls (subtract it per launch)."""
         return float(self._L.vsn_profile_bracket_ms(self._h))

@@ -292,6 +292,35 @@ def roofline_block(eng, nprof, workload, flops_step, ms_per_step):
     )
 
 
+MFMA_F32_SUSTAINED_TFLOPS = 116.0  # measured: what the fp32 matrix pipes sustain on real operands (power-limited clock;
+                                   # the 128 x 128 batch tile and the GEMM library alike, LAB_NOTES 4.1b)
+HBM_SUSTAINED_GBPS = 6300.0        # measured: a float4 device copy
+
+
+def step_bound(eng, nprof):
+    """sum over the instrumented launches of one step of max(flop / 116 TFLOP/s, algorithmic bytes / 6.3 TB/s) - what
+    the step would take with every GEMM launch at the sustained fp32 matrix rate and every node walk at the sustained
+    HBM rate - beside the time those launches actually took (the once-per-step launches - graph build, embeddings,
+    read-out, cap-hydrogen relaxation, integrator: ~20 launches at the 5-9 us floor of a dependent kernel - are neither
+    in the bound nor in `covered_ms`)."""
+    prof = eng.profile_read()
+    br_ms = eng.profile_bracket_ms()
+    walks = eng.profile_read_walks()
+    bound = meas = 0.0
+    for v in prof.values():
+        if v["launches"] > 0:
+            # per launch: the group's flops and bytes (averaged over the launches of the kernel)
+            fl, by, n = v["flops"] / v["launches"], v["bytes"] / v["launches"], v["launches"]
+            bound += n * max(fl / (MFMA_F32_SUSTAINED_TFLOPS * 1e12), by / (HBM_SUSTAINED_GBPS * 1e9)) * 1e3
+            meas += v["ms"] - n * br_ms
+    for v in walks.values():
+        if v["launches"] > 0:
+            bound += (v["bytes"] / (HBM_SUSTAINED_GBPS * 1e9)) * 1e3
+            meas += v["ms"]
+    return dict(step_bound_ms=bound / nprof, covered_ms=meas / nprof,
+                rule="sum over GEMM and node-walk launches of max(flop / 116 TFLOP/s, bytes / 6.3 TB/s)")
+
+
 def rocprof_from_profile(workload, kernel):
     """avg / min duration of `kernel` in the committed rocprofv3 kernel trace of this command on THIS build
     (profiles/r*_pmc_traffic.json, section "kernel_ns"; None when the library is another build)"""
@@ -315,13 +344,14 @@ def roofline_hbm_block(eng, nprof, workload):
     `achieved` = ALGORITHMIC bytes per launch (every array the launch touches, once: DESIGN.md 4.2) / average launch
     time; `traffic` = the PMC bytes of the same kernel from profiles/ (above the algorithmic bytes = re-reads);
     `rocprof` = the same kernel's avg / min in the committed kernel trace of this build, with the live / trace ratio."""
-    sp = eng.profile_read_scatter()
-    sp = {k: v for k, v in sp.items() if v["launches"] > 0}
+    walks = eng.profile_read_walks()
+    walks = {k: v for k, v in walks.items() if v["launches"] > 0}
+    sp = {k: v for k, v in walks.items() if k in ("k_edge_attn", "k_node_update")}
     if not sp:
         return None
     dom = max(sp, key=lambda k: sp[k]["ms"])
     blocks = {}
-    for k, v in sp.items():
+    for k, v in walks.items():
         n = v["launches"]
         us = max(1e3 * v["ms"] / n, 1e-3)
         gbps = (v["bytes"] / n) / (us * 1e-6) / 1e9
@@ -332,6 +362,11 @@ def roofline_hbm_block(eng, nprof, workload):
             blocks[k]["rocprof"] = dict(avg_us=rp["avg_ns"] / 1e3, min_us=rp["min_ns"] / 1e3,
                                         live_over_trace=us / (rp["avg_ns"] / 1e3),
                                         frac_from_trace=(v["bytes"] / n) / (rp["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBPS)
+        tr, _ = traffic_from_profile(workload, k)
+        if tr:
+            blocks[k]["traffic"] = tr
+            blocks[k]["traffic_over_algorithmic"] = tr / (v["bytes"] / n)
+    reverse = {k: blocks.pop(k) for k in list(blocks) if k.startswith("k_bwd_")}
     traffic, tnote = traffic_from_profile(workload, dom)
     d = blocks[dom]
     out = dict(bound="hbm", kernel=f"vsn::{dom}", achieved=d["achieved_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s",
@@ -341,6 +376,14 @@ def roofline_hbm_block(eng, nprof, workload):
                all_scatter_kernels=blocks)
     if "rocprof" in d:
         out["rocprof"] = d["rocprof"]
+    if reverse:
+        # the reverse node walks of single-protein sizes (hand-derived adjoints of visnet_block.py:237-312): same timing,
+        # algorithmic bytes per launch (every distinct array once, csrc/engine.hip), counter bytes beside them
+        out["reverse_walks_detail"] = reverse
+        out["reverse_walks"] = {k: dict(us=v["avg_launch_us"], per_step=v["launches_per_step"],
+                                        alg_MB=v["algorithmic_bytes_per_launch"] / 1e6,
+                                        pmc_MB=(v["traffic"] / 1e6 if "traffic" in v else None),
+                                        frac=v["frac"]) for k, v in reverse.items()}
     return out
 
 
@@ -447,6 +490,7 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
     wkey = f"{pname}_md" if (H, L) == (256, 9) else f"{pname}_md_h{H}l{L}"
     roof = roofline_block(eng, nprof, wkey, flops_step, ms)
     roof_hbm = roofline_hbm_block(eng, nprof, wkey)
+    bound = step_bound(eng, nprof)
     eng.set_option("profile", 0)
     workload = (f"{pname} AIMD loop: {len(prot)} atoms, B={len(plan.start)} fragments, N={len(plan.z)} fragment "
                 f"atoms, {'cap-H L-BFGS relaxation every step, ' if hplan is not None else ''}"
@@ -461,7 +505,10 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
     if requested_run:
         res["config"]["requested_run"] = requested_run
     if roof_hbm:
+        res["roofline"]["reverse_walks"] = roof_hbm.pop("reverse_walks", None)
+        res["roofline"]["reverse_walks_detail"] = roof_hbm.pop("reverse_walks_detail", None)
         res["roofline"]["hbm"] = roof_hbm
+    res["roofline"]["step_bound"] = bound
     return res, (plan, prot, md)
 
 
@@ -1043,7 +1090,9 @@ def compact_line(full: dict, detail_path: str | None = None, limit: int = LINE_L
                 ch["rocprof"] = _pick(h["rocprof"], ("avg_us", "frac_from_trace", "live_over_trace"))
             cr["hbm"] = ch
         if isinstance(r.get("reverse_walks"), dict):
-            cr["reverse_walks"] = r["reverse_walks"]
+            cr["reverse_walks"] = _short(r["reverse_walks"], sig=4)
+        if isinstance(r.get("step_bound"), dict):
+            cr["step_bound"] = _pick(r["step_bound"], ("step_bound_ms", "covered_ms"))
         c["roofline"] = cr
     if "cpu_baseline" in full:
         b = full["cpu_baseline"]

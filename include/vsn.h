@@ -107,6 +107,13 @@ int vsn_profile_read(vsn_handle h, double* out16);
  * (replaces reading torch_scatter / MessagePassing.propagate time off a profiler in the reference,
  *  ViSNet/model/visnet_block.py:276-312) */
 int vsn_profile_read_scatter(vsn_handle h, double* out8);
+/* The same records for ALL timed node walks: v = 0, 1 as above; 2 = k_bwd_hf1 (reverse vector messages, both sides,
+ * + the per-edge half and the source side of the edge-update adjoint), 3 = k_bwd_hf2 (reverse attention target side
+ * + the per-node half of the edge-update adjoint), 4 = k_bwd_attn_S, 5 = k_bwd_norm_update (LayerNorm adjoint + node
+ * update adjoint) - the hand-derived reverse of visnet_block.py:237-312 at single-protein sizes.  Every launch
+ * carries two events on its own dispatch packet (begin..end timestamps, no bracket correction).  Writes
+ * min(max_kinds, 6) rows of 4 doubles {launches, total ms, total algorithmic bytes, 0}; returns the rows written. */
+int vsn_profile_read_walks(vsn_handle h, double* out, int max_kinds);
 /* Average time (ms) between the two events of an EMPTY bracket on the launch stream, measured in the same profiled
  * calls (8 per chunk): what the bracket itself adds to every per-launch figure above.  0 when nothing was measured. */
 double vsn_profile_bracket_ms(vsn_handle h);

@@ -15,8 +15,13 @@ for rep in 1 2; do
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    h = d["roofline"].get("hbm", {}).get("all_scatter_kernels", {})
-    print("%-60s %8.2f %s | gemm %6.2f us | node_upd %5.2f | dF %.3e" % (sys.argv[2], d["value"], d["unit"], d["roofline"]["avg_launch_us"], h.get("k_node_update", {}).get("avg_launch_us", 0), d["parity_max_dF"]))
+    r = d["roofline"]
+    w = r.get("reverse_walks") or {}
+    us = lambda k: (w.get(k) or {}).get("us", 0)
+    print("%-44s %8.2f %s | gemm %6.2f us | %s %5.2f | hf1 %5.2f hf2 %5.2f attn_S %5.2f norm_upd %5.2f | dF %.3e" % (
+        sys.argv[2], d["value"], d["unit"], r["avg_launch_us"], r.get("hbm", {}).get("kernel", "?")[5:],
+        r.get("hbm", {}).get("avg_launch_us", 0), us("k_bwd_hf1"), us("k_bwd_hf2"), us("k_bwd_attn_S"),
+        us("k_bwd_norm_update"), d["parity"]["max_dF"]))
 except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY

@@ -40,10 +40,14 @@ from ai2bmd_amd.build import _digest
 res = {}
 want = {
     "chig_md": ("chig", [("k_gemm_group", "k_gemm_group"), ("k_node_update<", "k_node_update"),
-                         ("k_edge_attn", "k_edge_attn"), ("k_bwd_hf1", "k_bwd_hf1")]),
+                         ("k_edge_attn", "k_edge_attn"), ("k_bwd_hf1", "k_bwd_hf1"), ("k_bwd_hf2", "k_bwd_hf2"),
+                         ("k_bwd_attn_S", "k_bwd_attn_S"), ("k_bwd_norm_update", "k_bwd_norm_update")]),
     "frag_batch": ("batch", [("k_gemm<128; 128", "k_gemm<128,128>"), ("k_node_update<", "k_node_update"),
                              ("k_edge_attn<", "k_edge_attn"), ("k_bwd_gm_fused", "k_bwd_gm_fused"),
-                             ("k_bwd_gf_fused", "k_bwd_gf_fused")]),
+                             ("k_bwd_gf_fused", "k_bwd_gf_fused"), ("k_bwd_edge_update_T", "k_bwd_edge_update_T"),
+                             ("k_bwd_edge_update_S", "k_bwd_edge_update_S"), ("k_bwd_norm_update", "k_bwd_norm_update"),
+                             ("k_bwd_attn_S", "k_bwd_attn_S"), ("k_bwd_vecmsg_S", "k_bwd_vecmsg_S"),
+                             ("k_edge_update<", "k_edge_update")]),
 }
 for wl, (tag, pats) in want.items():
     rows = list(csv.DictReader(open(f"{out}/{tag}_pmc.csv")))
