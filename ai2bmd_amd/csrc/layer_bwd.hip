@@ -85,15 +85,12 @@ namespace vsn {
 
 int g_fuse_side = 2;  // single-protein sizes, reverse pass (env VSN_FUSE_SIDE): 2 = no second stream, the side kernels ride in
                       // main-chain launches (k_bwd_hf1/2); 1 = one fused side-stream launch per layer; 0 = three
-int g_merge_parts = 3;  // bit 0: k_bwd_hf1 runs its two target-side and its two source-side walks merged (2 parts
-                        // instead of 4); bit 1: k_bwd_hf2 runs its two walks merged (env VSN_MERGE_PARTS)
-int g_part_layout = 1;  // k_bwd_hf1 / k_bwd_hf2: how their parts map onto workgroups (see part_of_block; env VSN_PART_LAYOUT)
+int g_part_layout = 2;  // k_bwd_hf1 / k_bwd_hf2: how their parts map onto workgroups (see part_of_block; env VSN_PART_LAYOUT)
 int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
 static const bool g_bwd_env_read = [] {  // A/B switches, read once when the library is loaded
   if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);
   if (const char* e = getenv("VSN_FUSE_SIDE")) g_fuse_side = atoi(e);
   if (const char* e = getenv("VSN_PART_LAYOUT")) g_part_layout = atoi(e);
-  if (const char* e = getenv("VSN_MERGE_PARTS")) g_merge_parts = atoi(e);
   return true;
 }();
 // small batches (one protein per MD step): several waves per node
@@ -176,19 +173,18 @@ __global__ __launch_bounds__(256) void k_bwd_node_update(Dims D, const float* __
 // dE/dd sums, which each half adds into its own eight slots of the g_geo row (16..23 and 24..31; k_bwd_geom adds them).
 // PART: 0 = all of it; 1 = the per-edge outputs only (g_pf, dE/dd); 2 = the per-node sum g_wt only.  At single-protein
 // sizes the two halves ride in different launches of the main chain (k_bwd_hf1 / k_bwd_hf2) - each re-reads u2.
-// (the *_node functions are one node's share of a walk: the merged launches - k_bwd_hf1 / k_bwd_hf2 with
-//  g_merge_parts - run two of them on one fetch of the node's edge range and neighbour ids)
 template <int V, int S, int WPN, bool GEN, int CS = 1, int PART = 0>
-__device__ __forceinline__ void bwd_edge_update_T_node(const Dims& D, const float* __restrict__ vp,
+__device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const float* __restrict__ vp,
                                                        const float* __restrict__ pe, const float* __restrict__ g_f,
                                                        float* __restrict__ g_pe, float* __restrict__ g_vp,
                                                        float* __restrict__ g_geo, float* __restrict__ smem,
-                                                       const int i, const int e0, const int e1, const int srcc,
-                                                       const int lane, const int sub) {
+                                                       const int bid, const int nblk) {
   const int H = D.H;
   const int half = CS == 1 ? 0 : (int)blockIdx.y;
   const int co = half * 64 * V;  // first channel of this wave's share
-  {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float wt[S][V], gwt[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
@@ -256,7 +252,7 @@ __device__ __forceinline__ void bwd_edge_update_T_node(const Dims& D, const floa
         if (lane < S) g_geo[(size_t)e * VSN_GEO_W + 16 + 8 * half + lane] = geo_old + mine;  // own slots: may run next to vecmsg_T
       }
     }
-    if constexpr (PART == 1) return;
+    if constexpr (PART == 1) continue;
     if constexpr (WPN > 1 && S <= WPN && V <= 4) {
       // reduce-SCATTER: wave s ends up with the node total of component s and stores its own row (wave 0 summing
       // and storing all S rows alone while seven waves idle was ~20 % of k_bwd_hf1 at single-protein sizes)
@@ -272,18 +268,6 @@ __device__ __forceinline__ void bwd_edge_update_T_node(const Dims& D, const floa
     }
   }
 }
-template <int V, int S, int WPN, bool GEN, int CS = 1, int PART = 0>
-__device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const float* __restrict__ vp,
-                                                       const float* __restrict__ pe, const float* __restrict__ g_f,
-                                                       float* __restrict__ g_pe, float* __restrict__ g_vp,
-                                                       float* __restrict__ g_geo, float* __restrict__ smem,
-                                                       const int bid, const int nblk) {
-  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
-    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    const int srcc = edge_cache_load(D.src, e0, e1, lane);
-    bwd_edge_update_T_node<V, S, WPN, GEN, CS, PART>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, i, e0, e1, srcc, lane, sub);
-  }
-}
 
 template <int V, int S, int WPN, bool GEN, int CS = 1>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
@@ -295,13 +279,15 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T
 
 // ---- adjoint of the edge update, source side: g_ws_j = sum_{e: src=j} g_wd (u1 + a1 cc d) ----
 template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_edge_update_S_node(const Dims& D, const float* __restrict__ vp,
+__device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const float* __restrict__ vp,
                                                        const float* __restrict__ pe, const float* __restrict__ g_f,
                                                        float* __restrict__ g_vp, float* __restrict__ smem,
-                                                       const int j, const int t0, const int t1, const int permc,
-                                                       const int tgtc, const int lane, const int sub) {
+                                                       const int bid, const int nblk) {
   const int H = D.H;
-  {
+  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
+    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    const int permc = edge_cache_load(D.perm, t0, t1, lane);
+    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
     float gws[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -345,18 +331,6 @@ __device__ __forceinline__ void bwd_edge_update_S_node(const Dims& D, const floa
     }
   }
 }
-template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const float* __restrict__ vp,
-                                                       const float* __restrict__ pe, const float* __restrict__ g_f,
-                                                       float* __restrict__ g_vp, float* __restrict__ smem,
-                                                       const int bid, const int nblk) {
-  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
-    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
-    const int permc = edge_cache_load(D.perm, t0, t1, lane);
-    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
-    bwd_edge_update_S_node<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, j, t0, t1, permc, tgtc, lane, sub);
-  }
-}
 
 template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
@@ -370,13 +344,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S
 // mv_e[s] = vh_j[s] s1 + d_s s2 ; g_s1 = sum_s g_vec_i[s] vh_j[s] ; g_s2 = sum_s g_vec_i[s] d_s
 // g_t = [g_s1 silu'(t1) | g_s2 silu'(t2)] ; g_d[s] += sum_c g_vec_i[s] s2
 template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_vecmsg_T_node(const Dims& D, const float* __restrict__ g_vec,
+__device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __restrict__ g_vec,
                                                   const float* __restrict__ vh, const float* __restrict__ tpre,
-                                                  float* __restrict__ g_t, float* __restrict__ g_geo, const int i,
-                                                  const int e0, const int e1, const int srcc, const int lane,
-                                                  const int sub) {
+                                                  float* __restrict__ g_t, float* __restrict__ g_geo, const int bid,
+                                                  const int nblk) {
   const int H = D.H;
-  {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float gv[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
@@ -426,17 +401,6 @@ __device__ __forceinline__ void bwd_vecmsg_T_node(const Dims& D, const float* __
     }
   }
 }
-template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __restrict__ g_vec,
-                                                  const float* __restrict__ vh, const float* __restrict__ tpre,
-                                                  float* __restrict__ g_t, float* __restrict__ g_geo, const int bid,
-                                                  const int nblk) {
-  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
-    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    const int srcc = edge_cache_load(D.src, e0, e1, lane);
-    bwd_vecmsg_T_node<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, i, e0, e1, srcc, lane, sub);
-  }
-}
 
 template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
@@ -447,12 +411,14 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
 
 // ---- adjoint of the vector messages, source side: g_vh_j[s] = sum_{e: src=j} g_vec_tgt[s] s1_e ----
 template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_vecmsg_S_node(const Dims& D, const float* __restrict__ g_vec,
+__device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __restrict__ g_vec,
                                                   const float* __restrict__ tpre, float* __restrict__ g_vh,
-                                                  float* __restrict__ smem, const int j, const int t0, const int t1,
-                                                  const int permc, const int tgtc, const int lane, const int sub) {
+                                                  float* __restrict__ smem, const int bid, const int nblk) {
   const int H = D.H;
-  {
+  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
+    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
+    const int permc = edge_cache_load(D.perm, t0, t1, lane);
+    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
     float acc[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s)
@@ -486,17 +452,6 @@ __device__ __forceinline__ void bwd_vecmsg_S_node(const Dims& D, const float* __
     }
   }
 }
-template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __restrict__ g_vec,
-                                                  const float* __restrict__ tpre, float* __restrict__ g_vh,
-                                                  float* __restrict__ smem, const int bid, const int nblk) {
-  VSN_NODE_LOOP_B(j, D.N, WPN, bid, nblk) {
-    const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
-    const int permc = edge_cache_load(D.perm, t0, t1, lane);
-    const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
-    bwd_vecmsg_S_node<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, j, t0, t1, permc, tgtc, lane, sub);
-  }
-}
 
 template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
@@ -527,17 +482,18 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_side(
 // g_a[h] = sum_{c in h} gm v_j dv ; g_sat = g_a silu'(sat) C ; g_C += sum_h g_a silu(sat)
 // g_pk = g_sat q_i k_j silu'(pk) ; g_pv = gm v_j a silu'(pv) ; g_q_i = sum_e g_sat k_j dk
 template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_attn_T_node(const Dims& D, const float* __restrict__ qkv,
+__device__ __forceinline__ void bwd_attn_T_body(const Dims& D, const float* __restrict__ qkv,
                                                 const float* __restrict__ pe, const float* __restrict__ g_A,
                                                 float* __restrict__ g_m, float* __restrict__ g_pe,
                                                 float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
                                                 float* __restrict__ g_geo, const Parts mp, const Parts ap,
-                                                float* __restrict__ smem, const int i, const int e0, const int e1,
-                                                const int srcc, const int lane, const int sub) {
+                                                float* __restrict__ smem, const int bid, const int nblk) {
   const int H = D.H;
   const int nh = D.nh;
   const int lph = 64 / nh;
-  {
+  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
+    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
+    const int srcc = edge_cache_load(D.src, e0, e1, lane);
     float q[V], gA[V], gq[1][V];
     ldrow<V>(qkv + (size_t)i * 3 * H, lane, q);
     if (ap.n == 3) {  // dE/dA left as 3 K-slices by the GEMM: all loads first, then the sum in a fixed order
@@ -656,20 +612,6 @@ __device__ __forceinline__ void bwd_attn_T_node(const Dims& D, const float* __re
     if (sub == 0) strow<V>(g_qkv + (size_t)i * 3 * H, lane, gq[0]);
   }
 }
-template <int V, int S, int WPN, bool GEN>
-__device__ __forceinline__ void bwd_attn_T_body(const Dims& D, const float* __restrict__ qkv,
-                                                const float* __restrict__ pe, const float* __restrict__ g_A,
-                                                float* __restrict__ g_m, float* __restrict__ g_pe,
-                                                float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
-                                                float* __restrict__ g_geo, const Parts mp, const Parts ap,
-                                                float* __restrict__ smem, const int bid, const int nblk) {
-  VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
-    const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-    const int srcc = edge_cache_load(D.src, e0, e1, lane);
-    bwd_attn_T_node<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, i, e0, e1, srcc,
-                                    lane, sub);
-  }
-}
 
 template <int V, int S, int WPN, bool GEN>
 __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
@@ -722,32 +664,9 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN), ((WPN > 1 && V <= 4 && !
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
     float* __restrict__ g_t, float* __restrict__ g_geo, const float* __restrict__ vp, const float* __restrict__ pe,
     const float* __restrict__ g_f, float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_vh,
-    int with_eu, int il, int mg) {
+    int with_eu, int il) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int part, b, G;
-  if (with_eu && mg) {
-    // merged: the two target-side walks of a node on ONE fetch of its edge range and neighbour ids, likewise the two
-    // source-side walks - half the workgroups, each saving an index chain and a workgroup turnover (the launch time
-    // is the sum of the workgroup lives over the 512 resident slots)
-    part_of_block<2>(il, part, b, G);
-    if (part == 0) {
-      VSN_NODE_LOOP_B(i, D.N, WPN, b, G) {
-        const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-        const int srcc = edge_cache_load(D.src, e0, e1, lane);
-        bwd_vecmsg_T_node<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, i, e0, e1, srcc, lane, sub);
-        bwd_edge_update_T_node<V, S, WPN, GEN, 1, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, i, e0, e1, srcc, lane, sub);
-      }
-    } else {
-      VSN_NODE_LOOP_B(j, D.N, WPN, b, G) {
-        const int t0 = uni(D.colptr[j]), t1 = uni(D.colptr[j + 1]);
-        const int permc = edge_cache_load(D.perm, t0, t1, lane);
-        const int tgtc = (t0 + lane < t1) ? D.tgt[permc] : 0;
-        bwd_edge_update_S_node<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, j, t0, t1, permc, tgtc, lane, sub);
-        bwd_vecmsg_S_node<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, j, t0, t1, permc, tgtc, lane, sub);
-      }
-    }
-    return;
-  }
   if (with_eu) part_of_block<4>(il, part, b, G);
   else part_of_block<2>(il, part, b, G);
   if (part == 0) {
@@ -765,18 +684,8 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf2(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
     float* __restrict__ g_geo, Parts mp, Parts ap, const float* __restrict__ vp, const float* __restrict__ g_f,
-    float* __restrict__ g_vp, int il, int mg) {
+    float* __restrict__ g_vp, int il) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (mg) {  // merged: attention target side, then the per-node half of the edge update, same node, same edges
-    VSN_NODE_LOOP(i, D.N, WPN) {
-      const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
-      const int srcc = edge_cache_load(D.src, e0, e1, lane);
-      bwd_attn_T_node<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, i, e0, e1, srcc,
-                                      lane, sub);
-      bwd_edge_update_T_node<V, S, WPN, GEN, 1, 2>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, i, e0, e1, srcc, lane, sub);
-    }
-    return;
-  }
   int part, b, G;
   part_of_block<2>(il, part, b, G);
   if (part == 0) bwd_attn_T_body<V, S, WPN, GEN>(D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, mp, ap, smem, b, G);
@@ -1307,10 +1216,9 @@ int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const floa
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   const int with_eu = with_edge_update ? 1 : 0;
   const int il = g_part_layout == 2 ? 1 : 0;
-  const int mg = (g_merge_parts & 1) ? 1 : 0;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_hf1,
-                   ::go(((with_eu && !mg) ? 4 : 2) * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
-                        D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu, il, mg));
+                   ::go((with_eu ? 4 : 2) * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
+                        D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu, il));
   return 0;
 }
 int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A, float* g_m,
@@ -1319,10 +1227,9 @@ int launch_bwd_hf2(hipStream_t st, const Dims& D, const float* qkv, const float*
   const int w = pick_wpn(D.N);
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   const int il = g_part_layout == 2 ? 1 : 0;
-  const int mg = (g_merge_parts & 2) ? 1 : 0;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_hf2,
-                   ::go(mg ? node_grid(D.N, w) : 2 * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
-                        D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp, il, mg));
+                   ::go(2 * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
+                        D, qkv, pe, g_A, g_m, g_pe, g_qkv, sat_tmp, g_geo, g_m_parts, g_A_parts, vp, g_f, g_vp, il));
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_attn_S,
                    ::go(node_grid(D.N, w), node_block(w), node_lds(w, 2, D.H / 64), st, D, qkv, pe, g_m, sat_tmp, g_qkv));
   return 0;
