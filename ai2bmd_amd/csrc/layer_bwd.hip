@@ -85,7 +85,8 @@ namespace vsn {
 
 int g_fuse_side = 2;  // single-protein sizes, reverse pass (env VSN_FUSE_SIDE): 2 = no second stream, the side kernels ride in
                       // main-chain launches (k_bwd_hf1/2); 1 = one fused side-stream launch per layer; 0 = three
-int g_part_layout = 2;  // k_bwd_hf1 / k_bwd_hf2: how their parts map onto workgroups (see part_of_block; env VSN_PART_LAYOUT)
+int g_part_layout = 1;  // k_bwd_hf1 / k_bwd_hf2: how their parts map onto workgroups (see part_of_block; env VSN_PART_LAYOUT).
+                        // Measured (Chignolin, us per launch hf1 / hf2): 0: 27.7 / 18.8, 1: 27.6 / 19.3, 2: 33.0 / 24.6
 int g_split_channels = 1;  // k_bwd_edge_update_T: two waves per node, half the channels each (env VSN_SPLIT_CH=0 disables)
 static const bool g_bwd_env_read = [] {  // A/B switches, read once when the library is loaded
   if (const char* e = getenv("VSN_SPLIT_CH")) g_split_channels = atoi(e);

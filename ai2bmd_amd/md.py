@@ -22,7 +22,9 @@ KB = 8.617330337217213e-05    # ase.units.kB  (eV/K)
 MASSES = {1: 1.008, 6: 12.011, 7: 14.007, 8: 15.999, 16: 32.06}
 
 
-KCALMOL2EV = 0.0433641153087705   # (units.kcal / units.mol) / units.eV
+# (units.kcal / units.mol) / units.eV = 4184 / (_e * _Nav) with the CODATA 2014 table FS and KB above come from (ASE's
+# default since 3.17); the literature value 0.0433641153 (older CODATA) differs in the 7th digit
+KCALMOL2EV = 0.04336410390059322
 
 
 class TemperatureRunawayError(RuntimeError):
