@@ -121,6 +121,10 @@ struct vsn_ctx {
   // bit 0: forward edge update on the side stream, bit 1: reverse-pass side work.  Measured on Chignolin
   // (steps/s): none 339, forward only 327, reverse only 349, both 350 - a fork/join costs ~15 us of event latency,
   // more than the 11-16 us forward edge update it hides, so only the reverse pass (50-60 us of side work per layer) forks.
+  // bit 1 at single-protein sizes = the streamless form (side kernels ride in k_bwd_hf1 / k_bwd_hf2 of the main chain);
+  // bit 2 (round 5, default OFF) = fragment batches put the edge-update adjoints + source side of the vector messages on
+  // the side stream: 13.39 k fragments/s with, 13.39 k without (tools/lab/batch_ab.sh) - the fused panel products next
+  // to them just run twice as long (3.4 vs 2.0 ms), so the default keeps one stream.
   int overlap = 2;
   bool fuse_fwd = true, fuse_bwd_opt = true;
   bool fuse_head = true;  // fused node-local head kernel (head_fused.hip) on single-protein sizes
@@ -257,6 +261,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     // (fused.hip) and the 64x64 / split-K plain launches keep their fp32 MFMA kernels.
     c->gemm_split3 = value != 0;
     if (c->gemm_split3 && !c->s3) c->s3 = split3_table_create();
+  } else if (k == "panel_tp") {
+    set_panel_tp((int)value);  // process-wide (lab variant of the fused panel products, fused.hip)
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -1016,7 +1022,7 @@ static int run_chunk(vsn_ctx* c, hipStream_t st, const int64_t* z, const float* 
                        (bwd_batch_path(D) || (int64_t)Emax >= c->panel_min_edges);
     const bool streamless = (c->overlap & 2) && !c->debug && !l0 && bwd_streamless_ok(D) && !panel;
     // (a second stream only pays on batches: its fork / join costs ~7 us at each end, every layer)
-    const bool side_bw = (c->overlap & 2) && !c->debug && !l0 && !streamless && bwd_batch_path(D);
+    const bool side_bw = (c->overlap & 4) && !c->debug && !l0 && !streamless && bwd_batch_path(D);
     if (panel) {
       // edge-update adjoints + source side of the vector messages: on the side stream, or (overlap off) in line
       if (!l0) {

@@ -168,8 +168,14 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gm_fused(Dims D, const float* __
 // panels through the phases  gather(h=0) | mfma(0) | gather(1) | mfma(1) [| dma(2) | mfma(2)]  ONE TICK APART, with a
 // workgroup barrier per tick - by construction one team is in an MFMA phase while the other gathers, every tick.
 // The workgroup is persistent: it takes a contiguous range of panels (team 0 the even, team 1 the odd ones of the
-// range), so the alternation runs on across panels and the epilogue stores of a panel ride in its team's next
-// gather tick.  Same arithmetic in the same order as the kernels above: bitwise the same results.
+// range), so the alternation runs on across panels.  Same arithmetic in the same order as the kernels above: bitwise
+// the same results.
+// RESULT (MI355X, same lab script with VSN_PANEL_TP=1): gm 2.32 ms = 1.33 ms MFMA-only + 1.11 ms gather-only, gf 3.32 =
+// 2.13 + 1.71 - the phases STILL add up.  One MFMA wave per SIMD does saturate the matrix pipe (MFMA-only time
+// unchanged), but a SIMD whose matrix pipe is saturated issues next to nothing from its other wave: the gather of the
+// co-resident team only advances in the gaps.  Strict alternation therefore buys nothing over the free-running pair,
+// and the single gather wave per SIMD (unroll 1 to fit 256 registers) is slower than two: 13.4 k -> 12.7 k
+// fragments/s.  Kept as a lab variant (off by default); the fused products stay at MFMA + gather.
 template <bool GEN>
 __global__ __launch_bounds__(512, 1) void k_bwd_gm_fused_tp(Dims D, const float* __restrict__ g_vec,
                                                             const float* __restrict__ vh,
@@ -428,11 +434,13 @@ static inline void panel_lds(K kern, int bytes = 65536) {
   if (ndone < 64) done[ndone++] = Key{dev, (const void*)kern};
 }
 
-// env VSN_PANEL_TP (A/B aid): 1 (default) = the persistent team-phased kernels, 0 = one workgroup per panel
+// env VSN_PANEL_TP (A/B aid): 1 = the persistent team-phased kernels, 0 (default: measured faster, see k_bwd_gm_fused_tp)
+// = one workgroup per panel
 static int g_panel_tp = [] {
   const char* e = getenv("VSN_PANEL_TP");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }();
+void set_panel_tp(int v) { g_panel_tp = v; }  // process-wide lab switch (vsn_set_option "panel_tp")
 static int tp_grid() {  // one persistent workgroup per CU of the current device
   static thread_local int cus[64] = {0};
   int dev = 0;

@@ -91,13 +91,20 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     *reinterpret_cast<s3_bf16x8*>(base + PLANE) = m;
     *reinterpret_cast<s3_bf16x8*>(base + 2 * PLANE) = l;
   };
-  s3_bf16x8 bn[2][3], bc[2][3];
-  auto gloadB = [&](int kt) {
+  // B fragments: a register ring of THREE k-tiles (no copies: the loop below is unrolled over the ring positions) - the
+  // loads of k-tile kt + 2 are issued when kt starts, two k-tiles of MFMAs before their first use.
+  // [-DVSN_S3_BRING=1: one k-tile ahead, the round-4 form, for A/B builds.]
+#ifndef VSN_S3_BRING
+#define VSN_S3_BRING 2
+#endif
+  typedef s3_bf16x8 BFrag[2][3];
+  BFrag b0, b1, b2;
+  auto gloadB = [&](int kt, BFrag& dst) {
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        bn[kc][p] = *reinterpret_cast<const s3_bf16x8*>(bw + ((size_t)(kt * 2 + kc) * 3 + p) * 512);
+        dst[kc][p] = *reinterpret_cast<const s3_bf16x8*>(bw + ((size_t)(kt * 2 + kc) * 3 + p) * 512);
   };
   const bool accum = (flags & 1) != 0;
   const bool acc_out = accum && ksplit == 1;
@@ -117,7 +124,7 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   }
   const int fra = wm * 32 + l31;
-  auto mfma6 = [&](const unsigned char* st, int kc) {
+  auto mfma6 = [&](const unsigned char* st, int kc, const BFrag& bc) {
     const int c = kc * 2 + hi;
     s3_bf16x8 a[3];
 #pragma unroll
@@ -129,29 +136,41 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], bc[kc][0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bc[kc][0], acc, 0, 0, 0);
   };
-  gloadA(0);
-  gloadB(0);
-  sstoreA(0);
-  if (1 < nkt) gloadA(1);
-  __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
+  // one k-tile: multiply with `bc`, request k-tile kt + VSN_S3_BRING into `bl` (the ring slot that has just been freed)
+  auto step = [&](int kt, const BFrag& bc, BFrag& bl) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
-#pragma unroll
-    for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-      for (int p = 0; p < 3; ++p) bc[kc][p] = bn[kc][p];
-    if (kt + 1 < nkt) gloadB(kt + 1);
+    if (kt + VSN_S3_BRING < nkt) gloadB(kt + VSN_S3_BRING, bl);
     __builtin_amdgcn_sched_barrier(0);
-    mfma6(st, 0);
+    mfma6(st, 0, bc);
     if (kt + 1 < nkt) {  // tile kt+1 (in registers) -> the other stage; the loads of tile kt+2 start
       __builtin_amdgcn_sched_barrier(0);
       sstoreA((kt & 1) ^ 1);
       if (kt + 2 < nkt) gloadA(kt + 2);
       __builtin_amdgcn_sched_barrier(0);
     }
-    mfma6(st, 1);
+    mfma6(st, 1, bc);
     __syncthreads();
+  };
+  gloadA(0);
+  gloadB(0, b0);
+#if VSN_S3_BRING == 2
+  if (1 < nkt) gloadB(1, b1);
+#endif
+  sstoreA(0);
+  if (1 < nkt) gloadA(1);
+  __syncthreads();
+#if VSN_S3_BRING == 2
+  for (int kt = 0; kt < nkt; kt += 3) {
+    step(kt, b0, b2);
+    if (kt + 1 < nkt) step(kt + 1, b1, b0);
+    if (kt + 2 < nkt) step(kt + 2, b2, b1);
   }
+#else
+  for (int kt = 0; kt < nkt; kt += 2) {
+    step(kt, b0, b1);
+    if (kt + 1 < nkt) step(kt + 1, b1, b0);
+  }
+#endif
   float* __restrict__ Ct = ksplit == 1 ? C + (size_t)row0 * ldc + col0 : part + ((size_t)ks * M + row0) * Nc + col0;
   const unsigned ldo = (unsigned)(ksplit == 1 ? ldc : Nc);
   const unsigned off = (unsigned)(wm * 32 + 4 * hi) * ldo + (unsigned)(wn * 32 + l31);

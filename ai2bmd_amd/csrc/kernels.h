@@ -142,6 +142,7 @@ Split3Table* split3_table_create();
 void split3_table_destroy(Split3Table* t);
 void set_gemm_split3(Split3Table* t);  // thread-local; nullptr (default) = fp32 MFMA products
 
+void set_panel_tp(int v);  // fused.hip: 1 = persistent team-phased fused panel products (lab variant), 0 = default
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
 // independent products in one launch (falls back to separate launches when not worthwhile)

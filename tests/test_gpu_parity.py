@@ -502,7 +502,7 @@ def test_batch_path_option_matrix(lib_built, acts):
     assert len(z) >= 4096
     m = model_for(hp, 4)
     ref = None
-    for overlap in (2, 0):
+    for overlap in (2, 0, 6):  # (6 = + the reverse-pass side stream on batches)
         for fuse in (1, 0):
             m.engine.set_option("overlap", overlap)
             m.engine.set_option("fuse_panel", fuse)
@@ -516,3 +516,10 @@ def test_batch_path_option_matrix(lib_built, acts):
                 np.testing.assert_allclose(f, ref[1], rtol=0, atol=2e-5)
     m.engine.set_option("overlap", 2)
     m.engine.set_option("fuse_panel", 1)
+    # the persistent team-phased form of the fused products (lab variant, fused.hip): same sums in the same order
+    m.engine.set_option("panel_tp", 1)
+    try:
+        e_tp, f_tp = m.dl_potential_loader(frag(z, pos, start, end))
+    finally:
+        m.engine.set_option("panel_tp", 0)
+    assert np.array_equal(e_tp, ref[0]) and np.array_equal(f_tp, ref[1])
