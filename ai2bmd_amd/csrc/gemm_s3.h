@@ -91,11 +91,12 @@ __device__ __forceinline__ void gemm_body3(const float* __restrict__ A, int lda,
     *reinterpret_cast<s3_bf16x8*>(base + PLANE) = m;
     *reinterpret_cast<s3_bf16x8*>(base + 2 * PLANE) = l;
   };
-  // B fragments: a register ring of THREE k-tiles (no copies: the loop below is unrolled over the ring positions) - the
-  // loads of k-tile kt + 2 are issued when kt starts, two k-tiles of MFMAs before their first use.
-  // [-DVSN_S3_BRING=1: one k-tile ahead, the round-4 form, for A/B builds.]
+  // B fragments: a register ring, the loop below unrolled over its positions (no copies).  VSN_S3_BRING = 1 (default):
+  // two slots, k-tile kt + 1 requested when kt starts.  = 2: three slots, kt + 2 requested when kt starts - the review's
+  // "B ring two k-tiles ahead"; measured (round 5): 24 more registers push the tile to 128 VGPRs + 16 spills at four
+  // workgroups per CU, k_gemm_group_s3 28.8 -> 39.8 us, Chignolin 471 -> 396 steps/s in the mode.  Rejected.
 #ifndef VSN_S3_BRING
-#define VSN_S3_BRING 2
+#define VSN_S3_BRING 1
 #endif
   typedef s3_bf16x8 BFrag[2][3];
   BFrag b0, b1, b2;

@@ -179,7 +179,7 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
                                                        const float* __restrict__ pe, const float* __restrict__ g_f,
                                                        float* __restrict__ g_pe, float* __restrict__ g_vp,
                                                        float* __restrict__ g_geo, float* __restrict__ smem,
-                                                       const int bid, const int nblk, const int ehalf = -1) {
+                                                       const int bid, const int nblk) {
   const int H = D.H;
   const int half = CS == 1 ? 0 : (int)blockIdx.y;
   const int co = half * 64 * V;  // first channel of this wave's share
@@ -198,10 +198,7 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
 #pragma unroll
       for (int c = 0; c < V; ++c) gwt[s][c] = 0.f;
     }
-    // ehalf >= 0 (k_bwd_hf1, PART 1 only - no per-node sum): this workgroup takes one half of the node's edges
-    const int emid = e0 + ((e1 - e0 + 1) >> 1);
-    const int elo = ehalf == 1 ? emid : e0, ehi = ehalf == 0 ? emid : e1;
-    for (int e = elo + sub; e < ehi; e += WPN) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
       float geo_old = 0.f;
       if constexpr (PART != 2)  // fetched early, see k_bwd_vecmsg_T
@@ -351,7 +348,7 @@ template <int V, int S, int WPN, bool GEN>
 __device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __restrict__ g_vec,
                                                   const float* __restrict__ vh, const float* __restrict__ tpre,
                                                   float* __restrict__ g_t, float* __restrict__ g_geo, const int bid,
-                                                  const int nblk, const int ehalf = -1) {
+                                                  const int nblk) {
   const int H = D.H;
   VSN_NODE_LOOP_B(i, D.N, WPN, bid, nblk) {
     const int e0 = uni(D.rowptr[i]), e1 = uni(D.rowptr[i + 1]);
@@ -359,9 +356,7 @@ __device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __
     float gv[S][V];
 #pragma unroll
     for (int s = 0; s < S; ++s) ldrow<V>(g_vec + ((size_t)i * S + s) * H, lane, gv[s]);
-    const int emid = e0 + ((e1 - e0 + 1) >> 1);  // ehalf >= 0: one half of the node's edges (per-edge outputs only)
-    const int elo = ehalf == 1 ? emid : e0, ehi = ehalf == 0 ? emid : e1;
-    for (int e = elo + sub; e < ehi; e += WPN) {
+    for (int e = e0 + sub; e < e1; e += WPN) {
       const int j = edge_cache_get(srcc, D.src, e, e0);
       // the running dE/dd of this edge: fetched with the other operands, not after the reductions (a load that is
       // issued only when the sum is ready stalls the wave for a full memory round trip per edge)
@@ -673,18 +668,6 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN), ((WPN > 1 && V <= 4 && !
     int with_eu, int il) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int part, b, G;
-  if (il == 3) {
-    // target-side walks (per-edge outputs, no per-node sum) as TWO workgroups per node, half the edges each: the life
-    // of the heaviest workgroups (degree 25..32: four edges per wave) halves.  Parts: [a.0 | a.1 | (b.0 | b.1 | c |) d]
-    if (with_eu) part_of_block<6>(0, part, b, G);
-    else part_of_block<3>(0, part, b, G);
-    const int last = with_eu ? 5 : 2;
-    if (part < 2) bwd_vecmsg_T_body<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, b, G, part);
-    else if (part == last) bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, b, G);
-    else if (part < 4) bwd_edge_update_T_body<V, S, WPN, GEN, 1, 1>(D, vp, pe, g_f, g_pe, g_vp, g_geo, smem, b, G, part - 2);
-    else bwd_edge_update_S_body<V, S, WPN, GEN>(D, vp, pe, g_f, g_vp, smem, b, G);
-    return;
-  }
   if (with_eu) part_of_block<4>(il, part, b, G);
   else part_of_block<2>(il, part, b, G);
   if (part == 0) {
@@ -1233,10 +1216,9 @@ int launch_bwd_hf1(hipStream_t st, const Dims& D, const float* g_vec, const floa
   const int w = pick_wpn(D.N);
   const bool g__ = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU || D.hgen;
   const int with_eu = with_edge_update ? 1 : 0;
-  const int il = g_part_layout == 2 ? 1 : (g_part_layout == 3 ? 3 : 0);
-  const int nparts = il == 3 ? (with_eu ? 6 : 3) : (with_eu ? 4 : 2);
+  const int il = g_part_layout == 2 ? 1 : 0;
   VSN_DISPATCH_VSA(D.H, D.S, w, g__, KL_k_bwd_hf1,
-                   ::go(nparts * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
+                   ::go((with_eu ? 4 : 2) * part_grid(D.N, w), node_block(w), node_lds(w, D.S, D.H / 64), st,
                         D, g_vec, vh, tpre, g_t, g_geo, vp, pe, g_f, g_pe, g_vp, g_vh, with_eu, il));
   return 0;
 }

@@ -14,6 +14,10 @@ cd "$R"
 cp "$OUT/pmc_traffic.json" "profiles/${TAG}_pmc_traffic.json"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench.err"
 echo "bench rc=$?"
+cp gpurun_out/bench_full_chig_md_n1.json "$OUT/bench_full.json" 2>/dev/null
+# the fragment batch alone (its own full record: atoms / edges per GPU for tools/walk_table.py)
+timeout 600 python bench.py --workload frag_batch --steps 6 --warmup 1 --no-cpu-baseline > "$OUT/bench_line_frag_batch.json" 2> "$OUT/bench_frag_batch.err"
+cp gpurun_out/bench_full_frag_batch_n1.json "$OUT/bench_full_frag_batch.json" 2>/dev/null
 python - "$OUT/bench_line.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
