@@ -21,7 +21,7 @@ cp gpurun_out/bench_full_frag_batch_n1.json "$OUT/bench_full_frag_batch.json" 2>
 python - "$OUT/bench_line.json" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print("value", d["value"], "steps", d["steps"], d["config"].get("requested_run", {}).get("value"))
+print("value", d["value"], "steps", d["steps"], "c2 loop", d["config"].get("c2_loop", {}).get("value"))
 r = d["roofline"]; print("gemm", r["kernel"], round(r["frac"], 4), round(r["avg_launch_us"], 2), "traffic", r["traffic"])
 h = r["hbm"]; print("hbm", h["kernel"], round(h["frac"], 4), round(h["avg_launch_us"], 2), "traffic", h["traffic"], h.get("rocprof"))
 c = d["cpu_baseline"]; print("cpu", {k: c[k] for k in ("value", "cores", "kind", "physical_cores", "layout_of_value", "reference_layout_evals_per_s")})
