@@ -598,7 +598,7 @@ def harvested_pool():
     return pool
 
 
-def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16):
+def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16, keep=None):
     """BASELINE configs[4] as stated - "Protein Unit Dataset throughput: 1M dipeptide conformations batched across
     the GPUs (pure force eval, no integrator)": `conformations` (default 1 000 000 over all ranks) NEW conformations,
     every one evaluated exactly once, in batches of --frags-per-gpu per rank.  Conformation = a fragment of the
@@ -712,6 +712,8 @@ def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16):
     el = ctx.max_over_ranks(time.perf_counter() - t0)
     k = nbatch
     assert state["consumed"] == nbatch and math.isfinite(state["sumE"]) and math.isfinite(state["sumF"])
+    if keep is not None:  # tests: the inputs of every batch, to re-evaluate them one by one outside the pipe
+        keep.update(z=z_all, pos=pn, start=start, end=end)
     ms = 1e3 * el / k
     E_tot = count_edges(pn[0], start, end, hp["cutoff"], hp["max_num_neighbors"])
     flops_batch = 2.0 * fwd_flops(natoms, E_tot, H, L, S, R)

@@ -184,3 +184,82 @@ def test_rccl_all_gather_path_on_one_gpu(setup):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_streamed_conformations_equal_their_one_by_one_evaluation(lib_built):
+    """bench.py's configs[4] pipe (run_frag_stream: pinned host batches, double-buffered H2D on a copy stream, evaluation,
+    D2H, host-side checksums, all overlapped) against the same batches evaluated one at a time with nothing in flight:
+    the float64 checksums of E and F agree to the last bit (same kernels, same inputs - a buffer reused too early or a
+    result read too soon would show), every batch is consumed exactly once, and the golden block is re-checked in
+    stream."""
+    import argparse
+
+    import bench
+    from ai2bmd_amd.synthetic import default_hparams, make_state_dict
+    from ai2bmd_amd.visnet_calculator import ViSNetEngine
+
+    hp = default_hparams()
+    eng = ViSNetEngine(hp, make_state_dict(hp, seed=2024), "cuda:0")
+    args = bench.parse_args(["--workload", "frag_stream", "--frags-per-gpu", "330", "--conformations", "2310"])
+    ctx = argparse.Namespace(dev="cuda:0", rank=0, world=1, barrier=torch.cuda.synchronize, max_over_ranks=lambda v: v)
+    keep = {}
+    r = bench.run_frag_stream(ctx, eng, hp, args, golden_every=3, keep=keep)
+    nb = r["steps"]
+    assert nb == 7 and r["config"]["conformations"] == 7 * 330 and r["parity"]["golden_blocks_checked"] == 3
+    assert r["parity"]["max_dF"] <= 1e-4
+    z = torch.as_tensor(keep["z"], dtype=torch.int64).cuda()
+    sE = sF = sF2 = 0.0
+    for b in range(nb):
+        pos = torch.as_tensor(keep["pos"][b]).cuda()
+        e = torch.empty(len(keep["start"]), device="cuda:0")
+        f = torch.empty(len(keep["z"]), 3, device="cuda:0")
+        eng.forces_device(z, pos, keep["start"], keep["end"], e, f)
+        torch.cuda.synchronize()
+        sE += float(e.cpu().numpy().sum(dtype=np.float64))
+        sF += float(np.abs(f.cpu().numpy()).sum(dtype=np.float64))
+        sF2 += float(np.square(f.cpu().numpy(), dtype=np.float64).sum())
+    c = r["config"]["checksum"]
+    assert c["sum_E"] == sE and c["sum_absF"] == sF and c["sum_F2"] == sF2, (c, sE, sF, sF2)
+
+
+def test_profile_mode_times_every_node_walk_with_its_byte_model(lib_built):
+    """vsn_profile_read_walks (bench.py's roofline.hbm / roofline.reverse_walks): in profile mode every node walk of a
+    single-protein evaluation - forward and reverse - carries an event pair on its own dispatch packet; launches per
+    evaluation follow the launch sequence of DESIGN.md section 5, every record has a positive time and the
+    algorithmic bytes of the formulas in csrc/engine.hip (= tools/walk_table.py), and the results are those of the
+    unprofiled run bit for bit."""
+    import sys
+
+    from ai2bmd_amd.synthetic import default_hparams as dh, make_state_dict as msd
+    from ai2bmd_amd.visnet_calculator import ViSNetEngine
+    from conftest import ROOT
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from walk_table import alg_floats
+
+    g = np.load(os.path.join(GOLDEN, "visnet_prot_chig.npz"))
+    hp = dh()
+    eng = ViSNetEngine(hp, msd(hp, seed=2024), "cuda:0")
+    z = torch.as_tensor(g["z"], dtype=torch.int64).cuda()
+    pos = torch.as_tensor(g["pos_relaxed"]).cuda()
+    e0 = torch.empty(len(g["start"]), device="cuda:0")
+    f0 = torch.empty(len(g["z"]), 3, device="cuda:0")
+    eng.forces_device(z, pos, g["start"], g["end"], e0, f0)
+    torch.cuda.synchronize()
+    E = eng.last_num_edges()
+    eng.set_option("profile", 1)
+    e1, f1 = torch.empty_like(e0), torch.empty_like(f0)
+    eng.forces_device(z, pos, g["start"], g["end"], e1, f1)
+    torch.cuda.synchronize()
+    w = eng.profile_read_walks()
+    eng.set_option("profile", 0)
+    assert torch.equal(e0, e1) and torch.equal(f0, f1)
+    L, n = hp["num_layers"], len(g["z"])
+    want = dict(k_edge_attn=L, k_node_update=L, k_bwd_hf1=L - 1, k_bwd_hf2=L - 2, k_bwd_attn_S=L, k_bwd_norm_update=L)
+    assert {k: int(v["launches"]) for k, v in w.items()} == want
+    assert all(v["ms"] > 0 and v["bytes"] > 0 for v in w.values())
+    for k in ("k_bwd_hf2", "k_bwd_attn_S", "k_node_update"):       # launches of one kind only: the model to the byte
+        assert w[k]["bytes"] == pytest.approx(4.0 * alg_floats(k, n, E) * want[k], rel=1e-12), k
+    # k_bwd_hf1: L - 2 launches with the edge update, one (the last layer) without
+    full = 4.0 * alg_floats("k_bwd_hf1", n, E)
+    assert (L - 2) * full < w["k_bwd_hf1"]["bytes"] < (L - 1) * full
