@@ -98,6 +98,11 @@ def parse_args(argv=None):
                          "device_strategy.py:84-127; default) or by edge count (measured: within 1 %% of each other, "
                          "DESIGN.md section 5 - the per-rank step is dominated by its size-independent part)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="VALIDATION aid, not a measurement: N ranks on ONE GPU (device = LOCAL_RANK %% device count) "
+                         "over gloo with device tensors - the real sharded product path (one HIP engine per rank, fused "
+                         "integrator halves, the all-gather, the remapped combine) where no multi-GPU node exists; "
+                         "RCCL itself refuses two ranks on one device")
     ap.add_argument("--stub", action="store_true",
                     help="launch-logic self-test on CPU (gloo, sleep-based fake step): NOT a measurement")
     a = ap.parse_args(argv)
@@ -132,17 +137,19 @@ class Ctx:
         self.stub = args.stub
         self.group = None
         self.backend = None
+        self.share_gpu = bool(getattr(args, "share_gpu", False))
         if self.stub:
             self.dev = "cpu"
         else:
-            torch.cuda.set_device(self.local_rank)
-            self.dev = f"cuda:{self.local_rank}"
+            idx = self.local_rank % max(torch.cuda.device_count(), 1) if self.share_gpu else self.local_rank
+            torch.cuda.set_device(idx)
+            self.dev = f"cuda:{idx}"
         if self.world > 1:
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            self.backend = "gloo" if self.stub else "nccl"  # "nccl" IS RCCL on ROCm
-            kw = {} if self.stub else dict(device_id=torch.device(self.dev))
+            self.backend = "gloo" if (self.stub or self.share_gpu) else "nccl"  # "nccl" IS RCCL on ROCm
+            kw = {} if self.backend == "gloo" else dict(device_id=torch.device(self.dev))
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world, **kw)
             self.dist = dist
 
@@ -482,6 +489,10 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
     # the workload must not change under the clock (a structure that flies apart has fewer edges = less work)
     assert abs(edges_after - edges_before) <= 0.1 * max(edges_before, 1), (edges_before, edges_after)
     assert torch.isfinite(md.x).all() and torch.isfinite(md.F).all(), "non-finite MD state"
+    # every rank integrates the whole protein from the same gathered forces: the trajectories must be THE SAME bits
+    chk = float(md.x.double().sum().item()) + float(md.v.double().sum().item()) if hasattr(md, "v") else float(md.x.double().sum().item())
+    spread = ctx.max_over_ranks(chk) + ctx.max_over_ranks(-chk)  # max - min over the ranks
+    assert spread == 0.0, f"ranks have diverged: checksum spread {spread!r} after {k} steps"
     ms = 1e3 * el / k
     n_loc = ff.local_rows
     # ---- instrumented pass: HIP events around every GEMM launch (same stream) ----
@@ -899,9 +910,11 @@ def main():
             eng.set_option(k_, int(v_))
         data = ("synthetic (seeded random weights at the reference's default hyper-parameters; "
                 "geometry = reference examples/*.pdb fixtures)")
+        if ctx.share_gpu:
+            data = "SHARED-GPU VALIDATION RUN (all ranks on one device over gloo): NOT a measurement; " + data
         if args.workload.endswith("_md"):
             n_main, pre = args.steps, None
-            if args.workload == "chig_md" and not args.emulate_shard:
+            if args.workload == "chig_md" and not args.emulate_shard and not args.share_gpu:
                 # BASELINE configs[1] IS the 1000-step loop: it is always timed; a shorter --steps K is timed first and is
                 # what `value` is quoted on (the driver's contract: EXACTLY K steps), the loop rides in config.c2_loop
                 n_main = max(args.steps, C2_STEPS)
