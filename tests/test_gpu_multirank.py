@@ -38,3 +38,72 @@ def test_sharded_md_with_real_ranks_on_one_gpu(lib_built, world, workload, steps
     # this rank's shard really is a shard
     full = dict(chig_md=391, ww_md=1387)[workload]
     assert 0 < out["config"]["frag_atoms_local"] < full
+
+
+WORKER_EMPTY = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from ai2bmd_amd.amber import load_tables
+from ai2bmd_amd.bonded import ShardedFragmentForces
+from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan
+from ai2bmd_amd.hydrogen import build_hydrogen_plan
+from ai2bmd_amd.md import LangevinHIP
+from ai2bmd_amd.synthetic import default_hparams, make_state_dict
+from ai2bmd_amd.visnet_calculator import ViSNetEngine
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.set_device(0)
+gold = os.path.join(sys.argv[1], "tests", "golden")
+d = np.load(os.path.join(gold, "protein_chig.npz"))
+m = (d["resnums"] <= 4) | (d["resnums"] == 12)      # ACE-TYR-TYR-ASP-NME: 5 fragments for 8 ranks
+rn = d["resnums"][m].copy(); rn[rn == 12] = 5
+pos0 = d["positions"][m].astype(np.float64).copy()
+pos0[rn == 5] += pos0[(rn == 4) & (d["names"][m] == "C")][0] - pos0[(rn == 5) & (d["names"][m] == "N")][0] + 1.3
+prot = ProteinAtoms(d["names"][m], d["resnames"][m], rn, d["numbers"][m], pos0)
+plan = build_plan(prot)
+hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(gold, "amber_tables.npz")))
+hp = default_hparams(embedding_dimension=128, num_layers=3)
+eng = ViSNetEngine(hp, make_state_dict(hp, seed=5), "cuda:0")
+x = torch.as_tensor(prot.positions, dtype=torch.float32, device="cuda:0")
+for hyd in (None, hplan):
+    ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, hydrogen=hyd)
+    one = ShardedFragmentForces.for_engine(eng, plan, rank=0, world=1, hydrogen=hyd)
+    E, F = ff.step(x)
+    E1, F1 = one.step(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(F).all() and torch.allclose(F, F1, rtol=0, atol=2e-5), (rank, float((F - F1).abs().max()))
+    assert abs(float(E) - float(E1)) <= 1e-4 * max(1.0, abs(float(E1)))
+    owns = ff.f1 - ff.f0
+    assert (ff.fused_tail is None) == (owns == 0)
+# MD: ranks that own nothing integrate through the unfused halves, the others through the fused ones - same bits
+ff = ShardedFragmentForces.for_engine(eng, plan, rank=rank, world=world, hydrogen=hplan)
+md = LangevinHIP(prot.numbers, prot.positions, ff.step, "cuda:0", seed=3, tether_k=5.0)
+for _ in range(25):
+    md.step()
+torch.cuda.synchronize()
+chk = torch.stack([md.x.double().sum(), md.v.double().sum(), md.F.double().sum()])
+lo, hi = chk.clone(), chk.clone()
+dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+assert torch.equal(lo, hi), (rank, (hi - lo).tolist())
+print(f"rank {rank} ok frags={ff.f1 - ff.f0} fused={md._ff is not None}", flush=True)
+dist.destroy_process_group()
+'''
+
+
+def test_ranks_that_own_nothing_with_real_engines(lib_built, tmp_path):
+    """Five fragments on eight real ranks (one GPU, gloo): three ranks own no fragment - zero-row plans and views, no
+    engine call - and still enter the all-gather; every rank's recombined forces equal the single-rank evaluation, and
+    after 25 Langevin steps (fused halves on the owning ranks, unfused on the empty ones) all eight trajectories are
+    bit-identical."""
+    script = tmp_path / "worker_empty.py"
+    script.write_text(WORKER_EMPTY)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script), ROOT],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    for k in range(8):
+        assert f"rank {k} ok" in r.stdout
+    assert r.stdout.count("frags=0 fused=False") == 3 and r.stdout.count("fused=True") == 5
