@@ -105,14 +105,26 @@ class DistanceFragment:
         if self.plan is None:
             raise RuntimeError("DistanceFragment.fragment(prot) has not been called")
         st = torch.cuda.current_stream(self.device)
-        x = torch.as_tensor(np.ascontiguousarray(_positions(prot), dtype=np.float32)).to(self.device)
-        rc = self._L.vsn_build_fragments(self._fp, C.c_void_p(x.data_ptr()), C.c_void_p(self._pos.data_ptr()),
+        pos = np.asarray(_positions(prot))
+        io = self.__dict__.get("_io")
+        if io is None or io[0].shape[0] != len(pos):
+            # persistent staging (host positions in, fragment positions out, every MD step): pinned buffers, one
+            # device copy of the protein, asynchronous copies on the launch stream, ONE synchronisation
+            io = self._io = (torch.empty(len(pos), 3, dtype=torch.float32).pin_memory(),
+                             torch.empty(len(pos), 3, dtype=torch.float32, device=self.device),
+                             torch.empty(self._pos.shape, dtype=torch.float32).pin_memory())
+        pin_x, dev_x, pin_out = io
+        pin_x.numpy()[...] = pos
+        dev_x.copy_(pin_x, non_blocking=True)
+        rc = self._L.vsn_build_fragments(self._fp, C.c_void_p(dev_x.data_ptr()), C.c_void_p(self._pos.data_ptr()),
                                          C.c_void_p(st.cuda_stream))
         if rc:
             raise RuntimeError(f"vsn_build_fragments failed ({rc})")
         if self.relaxer is not None:
             self.relaxer.run(self._pos, st)
-        return FragmentData(prot.fragments_z, self._pos.cpu().numpy(), prot.fragments_start, prot.fragments_end,
+        pin_out.copy_(self._pos, non_blocking=True)
+        st.synchronize()
+        return FragmentData(prot.fragments_z, pin_out.numpy().copy(), prot.fragments_start, prot.fragments_end,
                             prot.fragments_batch)
 
     def __del__(self):
