@@ -40,7 +40,7 @@ for pname in ("chig", "ww"):
                     md.step()
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=s):
                 md.step()
             torch.cuda.synchronize()
             for _ in range(20):
@@ -53,6 +53,7 @@ for pname in ("chig", "ww"):
             graph = 1e3 * (time.perf_counter() - t0) / n
             ok = bool(torch.isfinite(md.x).all())
         except Exception as e:
-            graph, ok = float("nan"), f"capture failed: {type(e).__name__}: {str(e)[:200]}"
+            print(f"{pname} rank {r}/{w}: eager {eager:.3f} ms/step; capture failed: {type(e).__name__}: {str(e)[:300]}", flush=True)
+            raise SystemExit(1)
         print(f"{pname} rank {r}/{w}: eager {eager:.3f} ms/step, graph replay {graph:.3f} ms/step ({ok})", flush=True)
         del md, ff
