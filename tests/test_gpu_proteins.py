@@ -262,3 +262,17 @@ def test_panel_path_forced_at_single_protein_size_matches_golden(model):
     finally:
         eng.set_option("panel_min_edges", 1 << 40)
     check(e, f, g["E_ref64_relaxed"], g["F_ref64_relaxed"], g["F_ref32_relaxed"])
+
+
+def test_c1_single_alanine_dipeptide_through_the_seam(model):
+    """BASELINE configs[0] on the HIP path: ONE ACE-ALA-NME fragment (22 atoms, B = 1 - the smallest launch geometry
+    the engine sees) through `dl_potential_loader`, against the fragment's rows of the reference-source golden."""
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+    from test_protein_golden import _c1_fragment
+
+    for tag in ("relaxed", "placed"):
+        hp, seed, z, pos, start, end, E64, F64, E32, F32 = _c1_fragment(tag)
+        assert seed == 2024
+        e, f = model.dl_potential_loader(FragmentData(z, pos, start, end, make_batch_index(start, end)))
+        assert e.shape == (1, 1) and f.shape == (22, 3)
+        check(e.reshape(-1), f, np.asarray(E64).reshape(-1), F64, F32)

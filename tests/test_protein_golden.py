@@ -58,3 +58,40 @@ def test_builder_chain_golden_equals_the_all_reference_chain():
         assert sorted(a["z"][s:e].tolist()) == sorted(b["z"][s:e].tolist())
     # the fp32 run of the same all-reference chain: the error floor the HIP path is compared with
     assert np.abs(a["Fprot32"] - a["Fprot64"]).max() < 1e-5
+
+
+def _c1_fragment(tag="relaxed"):
+    """BASELINE configs[0] / SURVEY 8(d) C1: the single alanine-dipeptide fragment ACE-ALA-NME (22 atoms), geometry =
+    the ALA-3 window of examples/trpcage.pdb with its cap hydrogens, = fragment 2 of the Trp-cage fragment batch; its
+    reference-source energy and forces are rows of tests/golden/visnet_prot_trpcage.npz (fragments are independent
+    model inputs: visnet.py:135-166 sums per `batch` id)."""
+    d = np.load(os.path.join(GOLDEN, "visnet_prot_trpcage.npz"))
+    a, b = int(d["start"][2]), int(d["end"][2])
+    z = d["z"][a:b]
+    assert b - a == 22 and sorted(z.tolist()) == sorted([6, 6, 8, 1, 1, 1] + [7, 1, 6, 1, 6, 1, 1, 1, 6, 8] + [7, 1, 6, 1, 1, 1])
+    hp = json.loads(str(d["hparams"]))
+    return (hp, int(d["weight_seed"]), z, d[f"pos_{tag}"][a:b], np.array([0]), np.array([22]),
+            d[f"E_ref64_{tag}"][2], d[f"F_ref64_{tag}"][a:b], d[f"E_ref32_{tag}"][2], d[f"F_ref32_{tag}"][a:b])
+
+
+def test_c1_single_alanine_dipeptide_on_cpu():
+    """configs[0] (plumbing, no GPU): ONE ACE-ALA-NME fragment, energy + forces by the REFERENCE's own model on CPU
+    (source tree here, oracle/_ref elsewhere) and by the oracle restatement, both as a batch of one, against the
+    fragment's rows of the Trp-cage reference-source golden."""
+    from oracle.ref_import import import_reference_create_model, reference_model_source
+
+    hp, seed, z, pos, start, end, E64, F64, E32, F32 = _c1_fragment()
+    sd = make_state_dict(hp, seed=seed)
+    E, F, _ = ViSNetOracle(hp, sd, torch.float64).energy_forces(z, pos, start, end)
+    np.testing.assert_allclose(E.reshape(-1), np.asarray(E64).reshape(-1), rtol=0, atol=1e-9 * max(1.0, abs(float(E64))))
+    np.testing.assert_allclose(F, F64, rtol=0, atol=1e-9)
+    if reference_model_source() is None:
+        pytest.skip("reference model not present")
+    model = import_reference_create_model()(hp)
+    model.load_state_dict({k: torch.as_tensor(np.asarray(v)) for k, v in sd.items()})
+    model = model.float().eval()
+    Er, Fr = model(dict(z=torch.as_tensor(z), pos=torch.as_tensor(pos), batch=torch.zeros(22, dtype=torch.int64)))
+    Er, Fr = Er.detach().numpy().reshape(-1), Fr.detach().numpy()
+    # fp32 reference alone vs in the 39-fragment batch: same arithmetic per fragment up to reduction order
+    assert abs(float(Er[0]) - float(E32)) <= 2e-5 * max(1.0, abs(float(E32))) and np.abs(Fr - F32).max() <= 5e-6
+    assert np.abs(Fr - F64).max() <= 1e-4 * max(1.0, np.abs(F64).max())
