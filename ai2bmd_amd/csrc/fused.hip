@@ -22,9 +22,18 @@
 
 namespace vsn {
 
-// LAB ONLY (env VSN_LAB_FUSED_ABL, wrong numbers on purpose): bit 0 = the fused products skip their gather prologue,
-// bit 1 = they skip the MFMA slices - what each phase costs alone (tools/lab/fused_phases.sh)
+// LAB BUILDS ONLY (-DVSN_LAB_ABL=1 through tools/build_variant.py, then env VSN_LAB_FUSED_ABL; wrong numbers on purpose):
+// bit 0 = the fused products skip their gather prologue, bit 1 = they skip the MFMA slices - what each phase costs
+// alone (tools/lab/fused_phases.sh).  The product build has no such switch: the constant below folds it away.
+#ifndef VSN_LAB_ABL
+#define VSN_LAB_ABL 0
+#endif
+#if VSN_LAB_ABL
 __device__ int d_fused_abl = 0;
+#define VSN_FUSED_ABL() d_fused_abl
+#else
+#define VSN_FUSED_ABL() 0
+#endif
 
 // like wave_multi_sum<8> (common.h) but over each 32-lane half of the wave: every lane ends with the total, over its
 // half, of component (lane & 7)
@@ -147,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gm_fused(Dims D, const float* __
   G::zero(acc);
   typename G::Ring ring;
   G::prefetch(ring, Bp, 512, 0, wave, lane);
-  const int abl = d_fused_abl;
+  const int abl = VSN_FUSED_ABL();
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();  // every wave is done reading slice 0
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gm_fused_tp(Dims D, const float*
   const int np = p_hi - p_lo;                       // panels of this workgroup
   const int mine = (np + 1 - team) >> 1;            // ... of this team (team 0: even offsets, team 1: odd ones)
   const int mine0 = (np + 1) >> 1;
-  const int abl = d_fused_abl;
+  const int abl = VSN_FUSED_ABL();
   typename G::Acc acc;
   typename G::Ring ring;
   // Every wave of the workgroup arrives at the same NUMBER of barriers (mine0 * 4 + 1), the two teams from different
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gf_fused(Dims D, const float* __
   G::zero(acc);
   typename G::Ring ring;
   G::prefetch(ring, Bp, K, 0, wave, lane);
-  const int abl = d_fused_abl;
+  const int abl = VSN_FUSED_ABL();
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gf_fused_tp(Dims D, const float*
   const int np = p_hi - p_lo;
   const int mine = (np + 1 - team) >> 1;
   const int mine0 = (np + 1) >> 1;
-  const int abl = d_fused_abl;
+  const int abl = VSN_FUSED_ABL();
   typename G::Acc acc;
   typename G::Ring ring;
   if (team) __syncthreads();  // (barrier bookkeeping: see k_bwd_gm_fused_tp)
@@ -406,10 +415,14 @@ static const bool g_fused_env = [] {
   return true;
 }();
 static void lab_push_abl() {  // (per device: once per process is enough for the lab runs, which use one GPU)
+#if VSN_LAB_ABL
   static bool done = false;
   if (done || !g_lab_abl) return;
   hipMemcpyToSymbol(HIP_SYMBOL(d_fused_abl), &g_lab_abl, sizeof(int));
   done = true;
+#else
+  (void)g_lab_abl;
+#endif
 }
 
 bool panel_ok(const Dims& D) {  // (head counts that divide 64: the fused prologues sum heads over lane groups)
