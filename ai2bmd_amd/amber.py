@@ -8,6 +8,9 @@ tests/golden/amber_tables.npz (the reference tree does not exist on the GPU box)
 """
 from __future__ import annotations
 
+import functools
+import os
+
 import numpy as np
 
 # residue name -> topology code  (utils/reference.py:7-34)
@@ -92,6 +95,22 @@ def load_tables(path):
         t["natom"] = int(t["natom"])
         t["ntypes"] = int(t["ntypes"])
     return out
+
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "amber_tables.npz")
+
+
+@functools.lru_cache(maxsize=2)
+def _tables_from(source):
+    if source is None:
+        return load_tables(_DATA)
+    return {f[:-7]: read_prmtop(os.path.join(source, f)) for f in sorted(os.listdir(source)) if f.endswith(".prmtop")}
+
+
+def default_tables():
+    """ACE-X-NME AMBER tables: read from the AI2BMD tree when AI2BMD_PRMTOP_DIR points at its
+    src/Fragmentation/prmtop (own .prmtop reader above), else the packaged conversion of the same files."""
+    return _tables_from(os.environ.get("AI2BMD_PRMTOP_DIR") or None)
 
 
 def protein_mm_parameters(prot, tables):

@@ -37,26 +37,28 @@ class DipeptideBondedCombiner:
     def energy_combine(dipeptides_energy, ACE_NMEs_energy):
         return np.float32(np.asarray(dipeptides_energy).sum() - np.asarray(ACE_NMEs_energy).sum())
 
-    _idx_cache: dict = {}
+    def __init__(self):
+        self._idx_host = {}   # per combiner: (data_ptr, version, length) of an index tensor -> its host copy
 
-    @classmethod
-    def _index(cls, idx):
+    def _index(self, idx):
         """recombination indices as host numpy: the fragmenter leaves torch tensors on the default device like the
-        reference's (distancefrag.py:347-353); they are fixed for a simulation, so the host copy is made once"""
+        reference's (distancefrag.py:347-353); they are fixed for a simulation, so the host copy is made once per
+        (storage, in-place version) and kept by THIS combiner only"""
         if isinstance(idx, np.ndarray):
             return idx
-        hit = cls._idx_cache.get(id(idx))
-        if hit is None or hit[0] is not idx:
-            arr = idx.detach().cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
-            if len(cls._idx_cache) > 64:
-                cls._idx_cache.clear()
-            hit = cls._idx_cache[id(idx)] = (idx, arr)
-        return hit[1]
+        if not torch.is_tensor(idx):
+            return np.asarray(idx)
+        key = (idx.device, idx.data_ptr(), idx._version, tuple(idx.shape))
+        hit = self._idx_host.get(key)
+        if hit is None:
+            if len(self._idx_host) >= 4:  # select + origin of one protein; a new protein replaces them
+                self._idx_host.clear()
+            hit = self._idx_host[key] = idx.detach().cpu().numpy()
+        return hit
 
-    @classmethod
-    def forces_combine(cls, prot_len, dipeptides_forces, ACE_NMEs_forces, select_index, origin_index):
-        cat = np.concatenate([np.asarray(dipeptides_forces), -np.asarray(ACE_NMEs_forces)])[cls._index(select_index)]
-        oi = cls._index(origin_index)
+    def forces_combine(self, prot_len, dipeptides_forces, ACE_NMEs_forces, select_index, origin_index):
+        cat = np.concatenate([np.asarray(dipeptides_forces), -np.asarray(ACE_NMEs_forces)])[self._index(select_index)]
+        oi = self._index(origin_index)
         # scatter_sum(cat, origin_index) (combiner.py:38-39) as three bincounts: rows are added in index order like
         # np.add.at, in float64 (np.add.at is an order of magnitude slower per call and this runs every MD step)
         return np.stack([np.bincount(oi, weights=cat[:, k], minlength=prot_len) for k in range(3)], 1).astype(np.float32)

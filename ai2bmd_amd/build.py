@@ -51,8 +51,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = _hipcc()
 
+    def unit_digest(src):  # one translation unit: its source, every header, its flags
+        h = hashlib.sha256()
+        for f in [src] + HEADERS:
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+        h.update(" ".join(FLAGS + PER_FILE_FLAGS.get(src, [])).encode())
+        return h.hexdigest()
+
     def cc(src):
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        ostamp, od = obj + ".stamp", unit_digest(src)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == od:
+            return obj  # unchanged since it was compiled: only the edited units are rebuilt
         cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -61,6 +72,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             print(r.stderr)
+        with open(ostamp, "w") as fh:
+            fh.write(od)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:

@@ -90,6 +90,8 @@ def lib() -> C.CDLL:
     L.vsn_profile_read_scatter.restype = C.c_int
     L.vsn_profile_read_walks.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     L.vsn_profile_read_walks.restype = C.c_int
+    L.vsn_walk_alg_bytes.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.vsn_walk_alg_bytes.restype = C.c_double
     L.vsn_profile_bracket_ms.argtypes = [vp]
     L.vsn_profile_bracket_ms.restype = C.c_double
     L.vsn_last_num_edges.argtypes = [vp]
@@ -127,6 +129,8 @@ def lib() -> C.CDLL:
     L.vsn_md_half1.restype = C.c_int
     L.vsn_md_half2.argtypes = [vp, f32p, f32p, f32p, vp]
     L.vsn_md_half2.restype = C.c_int
+    L.vsn_md_set_noise.argtypes = [vp, vp, vp]
+    L.vsn_md_set_noise.restype = C.c_int
     L.vsn_md_half1_build.argtypes = [vp, f32p, f32p, f32p, vp, f32p, vp]
     L.vsn_md_half1_build.restype = C.c_int
     L.vsn_md_combine_half2.argtypes = [vp, vp, f32p, f32p, f32p, f32p, f32p, vp]
@@ -166,8 +170,8 @@ def i64_ptr(a):
 
 EXPORTS = [
     "vsn_create", "vsn_destroy", "vsn_last_error", "vsn_load_weight", "vsn_finalize", "vsn_set_option",
-    "vsn_forces", "vsn_profile_read", "vsn_profile_read_scatter", "vsn_profile_read_walks", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
+    "vsn_forces", "vsn_profile_read", "vsn_profile_read_scatter", "vsn_profile_read_walks", "vsn_walk_alg_bytes", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_combine_plan_set_energy", "vsn_combine_with_energy", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
-    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_half1_build", "vsn_md_combine_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
+    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_set_noise", "vsn_md_half1_build", "vsn_md_combine_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
     "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",
 ]

@@ -262,7 +262,8 @@ extern "C" int vsn_set_option(vsn_handle c, const char* key, int64_t value) {
     c->gemm_split3 = value != 0;
     if (c->gemm_split3 && !c->s3) c->s3 = split3_table_create();
   } else if (k == "panel_tp") {
-    set_panel_tp((int)value);  // process-wide (lab variant of the fused panel products, fused.hip)
+    // team-phased fused panel products (fused.hip): a LAB-BUILD variant (-DVSN_LAB_ABL=1), absent from the product
+    if (set_panel_tp((int)value)) return fail(c, -22, "panel_tp exists in lab builds only (-DVSN_LAB_ABL=1)");
   } else if (k == "overlap") {
     c->overlap = (int)value;
   } else if (k == "profile") {
@@ -764,7 +765,7 @@ struct ScatterBracket {
     hipEventCreate(&r.a);
     hipEventCreate(&r.b);
     c->srecs.push_back(r);
-    push_launch_events(LaunchEvents{r.a, r.b});  // FIFO: taken by the next timed-capable launch of this thread
+    push_launch_events(LaunchEvents{r.a, r.b, kind});  // FIFO: taken by the next launch of THIS kind on this thread
   }
   ~ScatterBracket() {
     if (on) set_launch_events(nullptr);  // (a launch that was skipped must not leak its pair to a later one)
@@ -777,6 +778,60 @@ static void drop_scatter_records(vsn_ctx* c) {
     hipEventDestroy(r.b);
   }
   c->srecs.clear();
+}
+
+// ---------------------------------------------------------------------------------
+// THE byte model of the node walks (the only statement of it: the live figures of bench.py's roofline.hbm /
+// roofline.reverse_walks come from here through vsn_profile_read_walks, tools/walk_table.py calls it through ctypes)
+// ---------------------------------------------------------------------------------
+// Algorithmic (compulsory) HBM bytes of ONE launch of a node walk over n nodes and e edges: every distinct array the
+// launch reads or writes, once; 4-byte indices counted like floats (DESIGN.md sections 3 / 4).  f0 / f1 per kernel:
+//   k_node_update        f0 = 1: the next layer's LayerNorm / VecLayerNorm is fused in
+//   k_bwd_hf1            f0 = 1: with the edge-update halves (every layer but the last)
+//   k_bwd_hf2            f0 / f1 = K-slices of g_m / g_A summed by this consumer (split_rev; 0 counts as 1)
+//   k_bwd_norm_update    f0 = 1: accumulates into g_x / g_vec
+extern "C" double vsn_walk_alg_bytes(const char* kernel, int H_, int S_, int nh_, double n, double e, int f0, int f1) {
+  if (!kernel) return -1.0;
+  const double H = H_, S = S_, nh = nh_;
+  const std::string k(kernel);
+  double fl;
+  if (k == "k_edge_attn") {  // pe[dk|dv], C, src | qkv | m, A
+    fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1);
+  } else if (k == "k_edge_attn_update") {  // + pe[f], f r/w, d, vp[wt|ws]
+    fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1) + e * (3 * H + 8) + n * S * 2 * H;
+  } else if (k == "k_edge_update") {  // (batches: its own launch) pe[f], f r/w, d, src | vp[wt|ws]
+    fl = e * (3 * H + 8 + 1) + n * S * 2 * H;
+  } else if (k == "k_node_update") {  // tpre, d, src | vh, vp[vec1..3], o, x r/w, vec r/w (+ xn, xh, rstd, vh of the next layer)
+    fl = e * (2 * H + 8 + 1) + n * (S * H * (1 + 3 + 2) + 3 * H + 2 * H + 1) + (f0 ? n * (2 * H + 1 + S * H) : 0.0);
+  } else if (k == "k_bwd_hf1") {  // vector messages (both sides) [+ edge update: per-edge half, source side]
+    // read tpre[2H], d, src|tgt|perm, g_geo[0..S) r/w | vh, g_vec; write g_t[2H] | g_vh
+    fl = e * (2 * H + 8 + 3 + 2 * S + 2 * H) + n * (3 * S * H + 2);
+    // + read pe[f], g_f, g_geo[16..16+S) r/w | vp[wt|ws]; write g_pe[f] | g_vp[ws]
+    if (f0) fl += e * (2 * H + 2 * S + H) + n * (3 * S * H);
+  } else if (k == "k_bwd_hf2") {  // attention target side + edge update per-node half
+    // read pe[dk|dv], the K-slices of g_m, C, g_geo[8] r/w, src | qkv, the K-slices of g_A;
+    // write g_m, g_pe[dk|dv], sat_tmp | g_q   + read pe[f], g_f, d | vp[ws]; write g_vp[wt]
+    fl = e * (2 * H + std::max(f0, 1) * H + 1 + 2 + 1 + H + 2 * H + 2 * nh) + n * (3 * H + std::max(f1, 1) * H + H + 2) +
+         e * (2 * H + 8) + n * (2 * S * H);
+  } else if (k == "k_bwd_attn_S") {  // read pe[dk|dv], g_m, sat_tmp, perm|tgt | q; write g_k, g_v
+    fl = e * (3 * H + 2 * nh + 2) + n * (3 * H + 1);
+  } else if (k == "k_bwd_norm_update") {  // read g_xh, xn, rstd, o[2H], g_vh, vp[3H] (+ g_x, g_vec when accumulating);
+                                          // write g_x, g_vec, g_vp[3H], g_o[3H]
+    fl = n * (2 * H + 1 + 2 * H + S * H + 3 * S * H + H + S * H + 3 * S * H + 3 * H) + (f0 ? n * (H + S * H) : 0.0);
+  } else if (k == "k_bwd_gm_fused") {  // (batches) tpre, d, g_geo r/w, src|tgt | vh, g_vec; write g_m
+    fl = e * (2 * H + 8 + 2 * S + 2 + H) + n * 2 * S * H;
+  } else if (k == "k_bwd_gf_fused") {  // pe[dk|dv], g_m r/w, g_pe[f], C, g_geo r/w, ids, sat_tmp, g_f r/w | qkv, g_A
+    fl = e * (2 * H + 2 * H + H + 1 + 2 + 2 + 2 * nh + 2 * H) + n * 4 * H;
+  } else if (k == "k_bwd_edge_update_T") {
+    fl = e * (3 * H + 8 + 4 * S + 1) + n * 3 * S * H;
+  } else if (k == "k_bwd_edge_update_S") {
+    fl = e * (2 * H + 10) + n * 2 * S * H;
+  } else if (k == "k_bwd_vecmsg_S") {
+    fl = e * (H + 2) + n * 2 * S * H;
+  } else {
+    return -1.0;
+  }
+  return 4.0 * fl;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1241,37 +1296,10 @@ extern "C" int vsn_forces(vsn_handle c, const int64_t* dev_z, const float* dev_p
         hipEventDestroy(r.a);
         hipEventDestroy(r.b);
         if (!timed) continue;
-        const double H = c->H, S = c->S, n = r.N, e = E, nh = c->nh;
-        double fl;  // floats: every distinct array the launch reads or writes, once (4-byte indices counted as floats)
-        switch (r.kind) {
-          case 0:  // edge attention (+ edge update): pe[dk|dv], C, src | qkv | m, A  (+ pe[f], f r/w, d, vp[wt|ws])
-            fl = e * (2 * H + 2 + H) + n * (3 * H + H + 1) + (r.f0 ? e * (3 * H + 8) + n * S * 2 * H : 0.0);
-            break;
-          case 1:  // node update: tpre, d, src | vh, vp[vec1..3], o, x r/w, vec r/w (+ next layer's xn, xh, rstd, vh)
-            fl = e * (2 * H + 8 + 1) + n * (S * H * (1 + 3 + 2) + 3 * H + 2 * H + 1) +
-                 (r.f0 ? n * (2 * H + 1 + S * H) : 0.0);
-            break;
-          case 2:  // k_bwd_hf1 = vector messages (both sides) [+ edge update: per-edge half, source side]
-            // read tpre[2H], d, src|tgt|perm, g_geo[0..S) r/w | vh, g_vec; write g_t[2H] | g_vh
-            fl = e * (2 * H + 8 + 3 + 2 * S + 2 * H) + n * (3 * S * H + 2);
-            // + read pe[f], g_f, g_geo[16..16+S) r/w | vp[wt|ws]; write g_pe[f] | g_vp[ws]
-            if (r.f0) fl += e * (2 * H + 2 * S + H) + n * (3 * S * H);
-            break;
-          case 3:  // k_bwd_hf2 = attention target side + edge update per-node half
-            // read pe[dk|dv], the K-slices of g_m, C, g_geo[8] r/w, src | qkv, the K-slices of g_A;
-            // write g_m, g_pe[dk|dv], sat_tmp | g_q   + read pe[f], g_f, d | vp[ws]; write g_vp[wt]
-            fl = e * (2 * H + std::max(r.f0, 1) * H + 1 + 2 + 1 + H + 2 * H + 2 * nh) +
-                 n * (3 * H + std::max(r.f1, 1) * H + H + 2) + e * (2 * H + 8) + n * (2 * S * H);
-            break;
-          case 4:  // k_bwd_attn_S: read pe[dk|dv], g_m, sat_tmp, perm|tgt | q; write g_k, g_v
-            fl = e * (3 * H + 2 * nh + 2) + n * (3 * H + 1);
-            break;
-          default:  // 5, k_bwd_norm_update: read g_xh, xn, rstd, o[2H], g_vh, vp[3H] (+ g_x, g_vec when accumulating);
-                    // write g_x, g_vec, g_vp[3H], g_o[3H]
-            fl = n * (2 * H + 1 + 2 * H + S * H + 3 * S * H + H + S * H + 3 * S * H + 3 * H) +
-                 (r.f0 ? n * (H + S * H) : 0.0);
-            break;
-        }
+        static const char* const kname[6] = {"k_edge_attn", "k_node_update", "k_bwd_hf1", "k_bwd_hf2", "k_bwd_attn_S",
+                                              "k_bwd_norm_update"};
+        const char* nm = (r.kind == WK_EDGE_ATTN && r.f0) ? "k_edge_attn_update" : kname[r.kind];
+        const double fl = vsn_walk_alg_bytes(nm, c->H, c->S, c->nh, r.N, E, r.f0, r.f1) / 4.0;
         c->sprof[r.kind][0] += 1;
         c->sprof[r.kind][1] += ms;
         c->sprof[r.kind][2] += 4.0 * fl;

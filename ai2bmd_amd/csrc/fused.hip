@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gm_fused(Dims D, const float* __
   G::template store<0>(acc, g_m, 256, e0, Meff, wave, lane);
 }
 
-// ---- the same product as a PERSISTENT, TEAM-PHASED kernel (round 5) ------------------------------------------------
+// ---- the same product as a PERSISTENT, TEAM-PHASED kernel (round 5; LAB BUILDS ONLY: -DVSN_LAB_ABL=1) -----------------
+#if VSN_LAB_ABL
 // Measured on the 4096-fragment batch (tools/lab/fused_phases.sh, products alone): k_bwd_gm_fused 1.97 ms = 1.34 ms
 // of MFMA slices + 0.77 ms of gather prologue; k_bwd_gf_fused 2.79 = 2.02 + 1.12.  The two resident workgroups of a
 // CU were meant to hide each other's prologue, but free-running they fall into step (both in the MFMA phase share
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gm_fused_tp(Dims D, const float*
   }
   if (!team) __syncthreads();
 }
+#endif  // VSN_LAB_ABL (team-phased lab variant)
 
 // ---------------------------------------------------------------------------------------------------------------
 // g_f[E,H] (+)= g_pe[E,3H] . We3    with the attention part of g_pe produced on the fly (adjoint of attention /
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gf_fused(Dims D, const float* __
   }
   G::template store<EPI>(acc, g_f, 256, e0, Meff, wave, lane);
 }
+#if VSN_LAB_ABL
 
 // persistent, team-phased form (see k_bwd_gm_fused_tp): phases per panel  gather(0) | mfma(0) | gather(1) | mfma(1)
 // and, with K = 768, | dma(2) | mfma(2) - gather-like and MFMA phases alternate, the teams run one tick apart
@@ -405,6 +408,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gf_fused_tp(Dims D, const float*
     for (int c = 0; c < C; ++c) __syncthreads();
   if (!team) __syncthreads();
 }
+#endif  // VSN_LAB_ABL (team-phased lab variant)
 
 // ---- hosts ------------------------------------------------------------------------------------------------
 static int g_fuse_panel = 1;  // env VSN_FUSE_PANEL=0: never take the fused / panel kernels (A/B aid)
@@ -430,9 +434,10 @@ bool panel_ok(const Dims& D) {  // (head counts that divide 64: the fused prolog
 }
 
 // the attribute is per DEVICE: remembered per (current device, kernel), so a thread that drives engines on several
-// GPUs sets it on each of them
+// GPUs sets it on each of them.  Returns false when the device refuses that much LDS per workgroup: the caller then
+// fails the evaluation instead of launching a kernel that cannot run (stale g_m / g_f would give wrong forces).
 template <typename K>
-static inline void panel_lds(K kern, int bytes = 65536) {
+static inline bool panel_lds(K kern, int bytes = 65536) {
   struct Key {
     int dev;
     const void* k;
@@ -442,18 +447,27 @@ static inline void panel_lds(K kern, int bytes = 65536) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   for (int i = 0; i < ndone; ++i)
-    if (done[i].dev == dev && done[i].k == (const void*)kern) return;
-  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (done[i].dev == dev && done[i].k == (const void*)kern) return true;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
   if (ndone < 64) done[ndone++] = Key{dev, (const void*)kern};
+  return true;
 }
+static inline int launched() { return hipGetLastError() == hipSuccess ? 0 : -1; }
 
-// env VSN_PANEL_TP (A/B aid): 1 = the persistent team-phased kernels, 0 (default: measured faster, see k_bwd_gm_fused_tp)
-// = one workgroup per panel
+#if VSN_LAB_ABL
+// env VSN_PANEL_TP / vsn_set_option "panel_tp" (LAB BUILDS ONLY, process-wide): 1 = the persistent team-phased kernels,
+// 0 (default: measured faster, see k_bwd_gm_fused_tp) = one workgroup per panel
 static int g_panel_tp = [] {
   const char* e = getenv("VSN_PANEL_TP");
   return e ? atoi(e) : 0;
 }();
-void set_panel_tp(int v) { g_panel_tp = v; }  // process-wide lab switch (vsn_set_option "panel_tp")
+int set_panel_tp(int v) {
+  g_panel_tp = v;
+  return 0;
+}
 static int tp_grid() {  // one persistent workgroup per CU of the current device
   static thread_local int cus[64] = {0};
   int dev = 0;
@@ -466,6 +480,9 @@ static int tp_grid() {  // one persistent workgroup per CU of the current device
   }
   return n;
 }
+#else
+int set_panel_tp(int v) { return v ? -1 : 0; }  // the team-phased variant does not exist in product builds
+#endif
 
 int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const float* vh, const float* tpre,
                         const float* WsTp, float* g_m, float* g_geo) {
@@ -473,25 +490,27 @@ int launch_bwd_gm_fused(hipStream_t st, const Dims& D, const float* g_vec, const
   lab_push_abl();
   const bool gen = D.act != VSN_ACT_SILU;
   const int grid = (D.Emax + 63) / 64;
+#if VSN_LAB_ABL
   if (g_panel_tp) {
     const int g = std::min(tp_grid(), (grid + 1) / 2);
     if (gen) {
-      panel_lds(k_bwd_gm_fused_tp<true>, 131072);
+      if (!panel_lds(k_bwd_gm_fused_tp<true>, 131072)) return -1;
       k_bwd_gm_fused_tp<true><<<g, 512, 131072, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
     } else {
-      panel_lds(k_bwd_gm_fused_tp<false>, 131072);
+      if (!panel_lds(k_bwd_gm_fused_tp<false>, 131072)) return -1;
       k_bwd_gm_fused_tp<false><<<g, 512, 131072, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
     }
-    return 0;
+    return launched();
   }
+#endif
   if (gen) {
-    panel_lds(k_bwd_gm_fused<true>);
+    if (!panel_lds(k_bwd_gm_fused<true>)) return -1;
     k_bwd_gm_fused<true><<<grid, 256, 65536, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
   } else {
-    panel_lds(k_bwd_gm_fused<false>);
+    if (!panel_lds(k_bwd_gm_fused<false>)) return -1;
     k_bwd_gm_fused<false><<<grid, 256, 65536, st>>>(D, g_vec, vh, tpre, WsTp, g_m, g_geo);
   }
-  return 0;
+  return launched();
 }
 
 int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const float* pe, const float* g_A,
@@ -501,16 +520,22 @@ int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const f
   lab_push_abl();
   const bool gen = D.act != VSN_ACT_SILU || D.attn_act != VSN_ACT_SILU;
   const int grid = (D.Emax + 63) / 64;
+#if VSN_LAB_ABL
+#define VSN_GF_TP(G_, E_)                                                                                           \
+  if (g_panel_tp) {                                                                                                 \
+    if (!panel_lds(k_bwd_gf_fused_tp<G_, E_>, 131072)) return -1;                                                   \
+    k_bwd_gf_fused_tp<G_, E_><<<std::min(tp_grid(), (grid + 1) / 2), 512, 131072, st>>>(                            \
+        D, qkv, pe, g_A, g_m, g_pe, sat_tmp, g_geo, We3Tp, g_f, K);                                                 \
+    return launched();                                                                                              \
+  }
+#else
+#define VSN_GF_TP(G_, E_)
+#endif
 #define VSN_GF(G_, E_)                                                                                              \
   do {                                                                                                              \
-    if (g_panel_tp) {                                                                                               \
-      panel_lds(k_bwd_gf_fused_tp<G_, E_>, 131072);                                                                 \
-      k_bwd_gf_fused_tp<G_, E_><<<std::min(tp_grid(), (grid + 1) / 2), 512, 131072, st>>>(                          \
-          D, qkv, pe, g_A, g_m, g_pe, sat_tmp, g_geo, We3Tp, g_f, K);                                               \
-    } else {                                                                                                        \
-      panel_lds(k_bwd_gf_fused<G_, E_>);                                                                            \
-      k_bwd_gf_fused<G_, E_><<<grid, 256, 65536, st>>>(D, qkv, pe, g_A, g_m, g_pe, sat_tmp, g_geo, We3Tp, g_f, K);  \
-    }                                                                                                               \
+    VSN_GF_TP(G_, E_)                                                                                               \
+    if (!panel_lds(k_bwd_gf_fused<G_, E_>)) return -1;                                                              \
+    k_bwd_gf_fused<G_, E_><<<grid, 256, 65536, st>>>(D, qkv, pe, g_A, g_m, g_pe, sat_tmp, g_geo, We3Tp, g_f, K);    \
   } while (0)
   if (gen) {
     if (accumulate) VSN_GF(true, 2);
@@ -520,7 +545,8 @@ int launch_bwd_gf_fused(hipStream_t st, const Dims& D, const float* qkv, const f
     else VSN_GF(false, 0);
   }
 #undef VSN_GF
-  return 0;
+#undef VSN_GF_TP
+  return launched();
 }
 
 }  // namespace vsn

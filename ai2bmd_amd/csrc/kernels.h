@@ -116,19 +116,24 @@ struct GemmProfiler {
 void set_gemm_profiler(GemmProfiler* p);  // thread-local; nullptr disables
 // profile mode, scatter path: the NEXT launch of k_edge_attn / k_edge_attn_update / k_node_update on this thread
 // carries these two events on its dispatch packet (their elapsed time = the kernel's begin..end timestamps)
+// Every queued pair is TAGGED with the walk it is meant for: a launch only takes a pair of its own kind, so routing
+// another launch through launch_maybe_timed (or skipping one) cannot charge time and bytes to the wrong kernel.
+enum WalkKind { WK_EDGE_ATTN = 0, WK_NODE_UPDATE = 1, WK_BWD_HF1 = 2, WK_BWD_HF2 = 3, WK_BWD_ATTN_S = 4, WK_BWD_NORM_UPDATE = 5 };
 struct LaunchEvents {
   hipEvent_t a, b;
+  int kind;  // WalkKind
 };
-// thread-local FIFO (layer_fwd.hip): every launch that goes through launch_maybe_timed takes the front pair, if any.
-// Timed-capable launches: k_edge_attn[_update], k_node_update (forward); k_bwd_hf1, k_bwd_hf2, k_bwd_attn_S,
-// k_bwd_norm_update (reverse walks).  set_launch_events(nullptr) empties the queue.
+// thread-local FIFO (layer_fwd.hip): a launch that goes through launch_maybe_timed(kind, ...) takes the front pair IF it
+// carries the same kind.  Timed-capable launches: k_edge_attn[_update], k_node_update (forward); k_bwd_hf1, k_bwd_hf2,
+// k_bwd_attn_S, k_bwd_norm_update (reverse walks).  set_launch_events(nullptr) empties the queue.
 void set_launch_events(const LaunchEvents* ev);  // nullptr: clear; else: clear + push one
 void push_launch_events(const LaunchEvents& ev);
-bool take_launch_events(LaunchEvents* out);
+bool take_launch_events(int kind, LaunchEvents* out);
 template <typename... KA, typename... A>
-static inline void launch_maybe_timed(void (*kern)(KA...), dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
+static inline void launch_maybe_timed(int kind, void (*kern)(KA...), dim3 g, dim3 b, unsigned lds, hipStream_t st,
+                                      A... a) {
   LaunchEvents ev;
-  if (take_launch_events(&ev)) {
+  if (take_launch_events(kind, &ev)) {
     hipExtLaunchKernelGGL<KA...>(kern, g, b, lds, st, ev.a, ev.b, 0, static_cast<KA>(a)...);
   } else {
     hipLaunchKernelGGL(kern, g, b, lds, st, static_cast<KA>(a)...);
@@ -142,7 +147,7 @@ Split3Table* split3_table_create();
 void split3_table_destroy(Split3Table* t);
 void set_gemm_split3(Split3Table* t);  // thread-local; nullptr (default) = fp32 MFMA products
 
-void set_panel_tp(int v);  // fused.hip: 1 = persistent team-phased fused panel products (lab variant), 0 = default
+int set_panel_tp(int v);  // fused.hip: team-phased fused panel products - LAB BUILDS ONLY (-1 when asked for in a product build)
 int launch_gemm(hipStream_t st, const float* A, int lda, const float* Bt, int ldb, float* C, int ldc,
                 const float* bias, int M, const int* Mptr, int Nc, int K, int flags);
 // independent products in one launch (falls back to separate launches when not worthwhile)

@@ -1186,23 +1186,23 @@ int launch_bwd_edge_update(hipStream_t st, const Dims& D, const float* vp, const
 bool bwd_streamless_ok(const Dims& D) { return g_fuse_side >= 2 && pick_wpn(D.N) != 1 && D.N > 0; }
 bool bwd_batch_path(const Dims& D) { return pick_wpn(D.N) == 1 && D.N > 0; }
 // (launch_maybe_timed: in profile mode these launches carry an event pair on their dispatch packet, kernels.h)
-#define VSN_KL4(NAME)                                                                      \
+#define VSN_KL4(NAME, KIND)                                                                \
   template <int V, int S, int W, bool G>                                                   \
   struct KL_##NAME {                                                                       \
     template <typename... A>                                                               \
     static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {                 \
-      launch_maybe_timed(NAME<V, S, W, G>, g, b, lds, st, a...);                           \
+      launch_maybe_timed(KIND, NAME<V, S, W, G>, g, b, lds, st, a...);                     \
     }                                                                                      \
   }
-VSN_KL4(k_bwd_hf1);
-VSN_KL4(k_bwd_hf2);
-VSN_KL4(k_bwd_attn_S);
+VSN_KL4(k_bwd_hf1, WK_BWD_HF1);
+VSN_KL4(k_bwd_hf2, WK_BWD_HF2);
+VSN_KL4(k_bwd_attn_S, WK_BWD_ATTN_S);
 #undef VSN_KL4
 template <int V, int S, int W>
 struct KL_k_bwd_norm_update {
   template <typename... A>
   static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {
-    launch_maybe_timed(k_bwd_norm_update<V, S, W>, g, b, lds, st, a...);
+    launch_maybe_timed(WK_BWD_NORM_UPDATE, k_bwd_norm_update<V, S, W>, g, b, lds, st, a...);
   }
 };
 // blocks per part of the multi-part launches: one per node, rounded up to whole XCD rounds unless layout 0

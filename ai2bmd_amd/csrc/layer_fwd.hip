@@ -558,22 +558,22 @@ void push_launch_events(const LaunchEvents& ev) {
   if (tl_ev_head == tl_ev_n) tl_ev_n = tl_ev_head = 0;
   if (tl_ev_n < 8) tl_ev_q[tl_ev_n++] = ev;
 }
-bool take_launch_events(LaunchEvents* out) {
-  if (tl_ev_head >= tl_ev_n) return false;
+bool take_launch_events(int kind, LaunchEvents* out) {
+  if (tl_ev_head >= tl_ev_n || tl_ev_q[tl_ev_head].kind != kind) return false;
   *out = tl_ev_q[tl_ev_head++];
   return true;
 }
-#define VSN_KL(NAME)                                                                       \
+#define VSN_KL(NAME, KIND)                                                                 \
   template <int V, int S, int W, bool G>                                                   \
   struct KL_##NAME {                                                                       \
     template <typename... A>                                                               \
     static void go(dim3 g, dim3 b, unsigned lds, hipStream_t st, A... a) {                 \
-      launch_maybe_timed(NAME<V, S, W, G>, g, b, lds, st, a...);                           \
+      launch_maybe_timed(KIND, NAME<V, S, W, G>, g, b, lds, st, a...);                     \
     }                                                                                      \
   }
-VSN_KL(k_edge_attn);
-VSN_KL(k_edge_attn_update);
-VSN_KL(k_node_update);
+VSN_KL(k_edge_attn, WK_EDGE_ATTN);
+VSN_KL(k_edge_attn_update, WK_EDGE_ATTN);
+VSN_KL(k_node_update, WK_NODE_UPDATE);
 #undef VSN_KL
 #define VSN_LAUNCH_ACT_TIMED(KN, RK, ...)                                                               \
   do {                                                                                                  \

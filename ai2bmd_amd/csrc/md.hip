@@ -71,12 +71,30 @@ __device__ __forceinline__ void normals6(unsigned long long seed, unsigned step,
   box_muller(r[0], r[1], z[4], z[5]);
 }
 
+// the step's (xi, eta) of atom i: the caller's draws when it supplied them (vsn_md_set_noise: the reference feeds ASE's
+// Langevin from utils/utils.py RNGPool, numpy normals - a trajectory can only be compared with ASE's on the SAME draws),
+// else the counter-based generator above
+__device__ __forceinline__ void noise6(unsigned long long seed, unsigned step, unsigned atom,
+                                       const float* __restrict__ ext_xi, const float* __restrict__ ext_eta,
+                                       float (&z)[6]) {
+  if (ext_xi) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      z[k] = ext_xi[3 * (size_t)atom + k];
+      z[3 + k] = ext_eta[3 * (size_t)atom + k];
+    }
+  } else {
+    normals6(seed, step, atom, z);
+  }
+}
+
 // single workgroup (proteins here have a few hundred to a few thousand atoms)
 __device__ __forceinline__ void md_half1_body(int n, const float* __restrict__ mass, const float* __restrict__ c3,
                                               const float* __restrict__ c4, const float* __restrict__ c5, float c1,
                                               float c2, float dt, unsigned long long seed, unsigned step,
                                               float* __restrict__ x, float* __restrict__ v,
-                                              const float* __restrict__ F, float* __restrict__ rnd_vel) {
+                                              const float* __restrict__ F, float* __restrict__ rnd_vel,
+                                              const float* __restrict__ ext_xi, const float* __restrict__ ext_eta) {
 #pragma clang fp contract(off)
   __shared__ float red[6][16];
   __shared__ float tot[6];
@@ -84,7 +102,7 @@ __device__ __forceinline__ void md_half1_body(int n, const float* __restrict__ m
   float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < n; i += blockDim.x) {
     float z[6];
-    normals6(seed, step, (unsigned)i, z);
+    noise6(seed, step, (unsigned)i, ext_xi, ext_eta, z);
     const float m = mass[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -108,7 +126,7 @@ __device__ __forceinline__ void md_half1_body(int n, const float* __restrict__ m
   const float invn = 1.0f / (float)n;
   for (int i = tid; i < n; i += blockDim.x) {
     float z[6];
-    normals6(seed, step, (unsigned)i, z);  // counter-based: regenerated, not stored
+    noise6(seed, step, (unsigned)i, ext_xi, ext_eta, z);  // counter-based (or caller-supplied): regenerated, not stored
     const float m = mass[i];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -130,8 +148,9 @@ __global__ __launch_bounds__(1024) void k_md_half1(int n, const float* __restric
                                                    const float* __restrict__ c5, float c1, float c2, float dt,
                                                    unsigned long long seed, unsigned step, float* __restrict__ x,
                                                    float* __restrict__ v, const float* __restrict__ F,
-                                                   float* __restrict__ rnd_vel) {
-  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel);
+                                                   float* __restrict__ rnd_vel, const float* __restrict__ ext_xi,
+                                                   const float* __restrict__ ext_eta) {
+  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel, ext_xi, ext_eta);
 }
 
 // half1 + the fragment-geometry gather of the NEW positions (the first kernel of the force evaluation that follows:
@@ -142,8 +161,10 @@ __global__ __launch_bounds__(1024) void k_md_half1_build(int n, const float* __r
                                                          unsigned long long seed, unsigned step,
                                                          float* __restrict__ x, float* __restrict__ v,
                                                          const float* __restrict__ F, float* __restrict__ rnd_vel,
-                                                         FragView fp, float* __restrict__ frag_pos) {
-  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel);
+                                                         const float* __restrict__ ext_xi,
+                                                         const float* __restrict__ ext_eta, FragView fp,
+                                                         float* __restrict__ frag_pos) {
+  md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel, ext_xi, ext_eta);
   __syncthreads();
   const float* xn = x;  // (x is written above: no __restrict__ promise on this read)
   for (int k = threadIdx.x; k < fp.n; k += blockDim.x) build_row(k, fp.src, fp.acc, fp.tow, fp.len, xn, frag_pos);
@@ -329,6 +350,7 @@ struct vsn_md {
   vsn::Spring* sp = nullptr;
   float* e_r = nullptr;           // [n] per-atom restraint energy of the last evaluation
   float* obs = nullptr;           // [4] observables
+  const float *ext_xi = nullptr, *ext_eta = nullptr;  // caller-supplied normal draws (vsn_md_set_noise), borrowed
 };
 
 static int set_springs(vsn_md* p, const std::vector<std::vector<vsn::Spring>>& per_atom) {
@@ -425,9 +447,16 @@ extern "C" int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const f
   if (!p) return -22;
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   hipLaunchKernelGGL(vsn::k_md_half1, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->n, p->mass, p->c3, p->c4, p->c5,
-                     p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel);
+                     p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel, p->ext_xi, p->ext_eta);
   p->step++;
   return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_set_noise(vsn_md_handle p, const float* dev_xi, const float* dev_eta) {
+  if (!p || ((dev_xi == nullptr) != (dev_eta == nullptr))) return -22;
+  p->ext_xi = dev_xi;   // borrowed: [n, 3] floats each, read by every following first half until reset with (NULL, NULL)
+  p->ext_eta = dev_eta;
+  return 0;
 }
 
 extern "C" int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, float* dev_F, void* stream) {
@@ -445,7 +474,8 @@ extern "C" int vsn_md_half1_build(vsn_md_handle p, float* dev_x, float* dev_v, c
   if (vsn_fragplan_view(plan, &fv) || fv.device != p->device) return -22;
   if (hipSetDevice(p->device) != hipSuccess) return -19;
   hipLaunchKernelGGL(vsn::k_md_half1_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, p->n, p->mass, p->c3, p->c4,
-                     p->c5, p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel, fv, dev_frag_pos);
+                     p->c5, p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F, p->rnd_vel, p->ext_xi, p->ext_eta,
+                     fv, dev_frag_pos);
   p->step++;
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -20,22 +20,10 @@ import numpy as np
 import torch
 
 from . import capi
-from .amber import load_tables, read_prmtop
+from .amber import default_tables  # noqa: F401  (re-exported: callers import it from here)
 from .fragment import FragmentData, make_batch_index
 from .fragmentation import ProteinAtoms, build_plan
 from .hydrogen import HydrogenRelaxer, build_hydrogen_plan
-
-_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "amber_tables.npz")
-
-
-def default_tables():
-    """ACE-X-NME AMBER tables: read from the AI2BMD tree when AI2BMD_PRMTOP_DIR points at its
-    src/Fragmentation/prmtop (own .prmtop reader, ai2bmd_amd/amber.py), else the packaged conversion of the same files."""
-    d = os.environ.get("AI2BMD_PRMTOP_DIR")
-    if d:
-        return {f[:-7]: read_prmtop(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith(".prmtop")}
-    return load_tables(_DATA)
-
 
 def as_protein_atoms(prot) -> ProteinAtoms:
     """`prot`: a ProteinAtoms, or an ase.Atoms-like object read from a PDB (arrays 'atomtypes', 'residuenames',
@@ -65,7 +53,8 @@ class DistanceFragment:
         from .device_strategy import DeviceStrategy
 
         p = as_protein_atoms(prot)
-        plan = build_plan(p)
+        plan = build_plan(p, tables=self.tables)
+        self._release()        # a second protein on the same instance: drop the previous plan's device state
         self.plan = plan
         prot.fragments_z = plan.z
         prot.fragments_start, prot.fragments_end = plan.start, plan.end
@@ -107,7 +96,7 @@ class DistanceFragment:
         st = torch.cuda.current_stream(self.device)
         pos = np.asarray(_positions(prot))
         io = self.__dict__.get("_io")
-        if io is None or io[0].shape[0] != len(pos):
+        if io is None or io[0].shape[0] != len(pos) or io[2].shape != self._pos.shape or io[1].device != self._pos.device:
             # persistent staging (host positions in, fragment positions out, every MD step): pinned buffers, one
             # device copy of the protein, asynchronous copies on the launch stream, ONE synchronisation
             io = self._io = (torch.empty(len(pos), 3, dtype=torch.float32).pin_memory(),
@@ -127,10 +116,13 @@ class DistanceFragment:
         return FragmentData(prot.fragments_z, pin_out.numpy().copy(), prot.fragments_start, prot.fragments_end,
                             prot.fragments_batch)
 
+    def _release(self):
+        if getattr(self, "_fp", None):
+            self._L.vsn_fragplan_destroy(self._fp)
+        self._fp = self._io = self.hplan = self.relaxer = None
+
     def __del__(self):
         try:
-            if getattr(self, "_fp", None):
-                self._L.vsn_fragplan_destroy(self._fp)
-                self._fp = None
+            self._release()
         except Exception:
             pass

@@ -17,12 +17,15 @@ Restates the behaviour of the reference's fragmenter
   /root/reference/src/Fragmentation/distancefrag.py:185-240,805-845 (CYX pairs: the two
         dipeptides of a disulfide bridge become ONE fragment in the slot of the
         first, the slot of the second stays empty)
-with one documented difference: atoms inside a fragment are ordered [previous-residue
-part | residue | next-residue part] instead of AMBER's order (the reference permutes with
-utils/seq_dict.pkl because its hydrogen optimiser needs AMBER topologies; ViSNet is
-permutation-equivariant, so energies/forces do not depend on it as long as no target
-exceeds max_num_neighbors; ai2bmd_amd/hydrogen.py maps rows to AMBER atoms by name and
-`hydrogen.amber_ordered(plan)` gives the reference's row order when it is wanted).
+Rows inside a fragment follow the REFERENCE's order by default (`order="amber"`): dipeptides in the atom order of
+their AMBER topology - what the reference's permutation with utils/seq_dict.pkl leaves behind
+(distancefrag.py:731-737) - and ACE-NME fragments as the first six atoms of the next dipeptide followed by the last
+six of the previous one (distancefrag.py:291-302).  `radius_graph` keeps the LOWEST-index `max_num_neighbors`
+sources of a target, so under neighbour truncation the forces depend on the row order: with the reference's order
+the FragmentData handed to the model is row for row the reference's and so is the truncated graph
+(tests/golden/refchain_*_nb*.npz).  Atoms are matched to template slots by NAME (ai2bmd_amd/hydrogen.py), so the
+protein itself may come in any atom order.  `order="grouped"` keeps the intermediate layout
+[previous-residue part | residue | next-residue part] the AMBER order is derived from (tests only).
 Pinned on the reference's own fragmenter (oracle/ref_fragmenter.py, tests/golden/fragref_*.npz).
 The per-step relaxation of the cap hydrogens is ai2bmd_amd/hydrogen.py + csrc/hydrogen.hip.
 """
@@ -88,6 +91,9 @@ class FragmentPlan:
     dip_row_start: np.ndarray = None  # int64 [n_dip]
     dip_row_end: np.ndarray = None    # int64 [n_dip]
     cyx_partner: np.ndarray = None    # int64 [n_dip]: dipeptide merged INTO this one (-1 none, -2 = this one was merged away)
+    # AMBER template slot of every dipeptide row (-1 on ACE-NME rows); set when the rows ARE in AMBER order, where it is
+    # the position inside the fragment (hydrogen.amber_ordered) - build_hydrogen_plan then takes it instead of names
+    tmpl_slot: np.ndarray = None      # int64 [Nf]
 
 
 def _residue_atom(p: ProteinAtoms, resnum: int, name: str) -> int:
@@ -97,7 +103,21 @@ def _residue_atom(p: ProteinAtoms, resnum: int, name: str) -> int:
     return int(hit[0])
 
 
-def build_plan(p: ProteinAtoms) -> FragmentPlan:
+def build_plan(p: ProteinAtoms, order: str = "amber", tables: dict = None) -> FragmentPlan:
+    """The fragment batch of protein `p`.  `order="amber"` (default): rows in the reference's order (module docstring);
+    `tables`: ACE-X-NME AMBER tables giving the atom order of every template (default: the packaged conversion of the
+    reference's .prmtop files, ai2bmd_amd.amber.default_tables)."""
+    if order == "grouped":
+        return _grouped_plan(p)
+    if order != "amber":
+        raise ValueError(f"order must be 'amber' or 'grouped', not {order!r}")
+    from .amber import default_tables
+    from .hydrogen import amber_ordered
+
+    return amber_ordered(p, _grouped_plan(p), tables if tables is not None else default_tables())
+
+
+def _grouped_plan(p: ProteinAtoms) -> FragmentPlan:
     nres = int(p.resnums.max())
     if len(set(p.resnums.tolist())) != nres:
         raise ValueError("residue numbers are not continuous")  # basefrag.py:67-69

@@ -119,6 +119,53 @@ def template_index_of_dipeptide(p: ProteinAtoms, plan: FragmentPlan, d: int, nam
     return out
 
 
+def template_slots(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> list:
+    """Per dipeptide FRAGMENT (slot d of the interleaved batch = fragment 2d): the AMBER template atom index of every
+    row.  A plan whose rows already are in AMBER order carries them (`plan.tmpl_slot`); otherwise atoms are matched to
+    the template by NAME.  Empty for a CYX dipeptide merged into its partner's fragment."""
+    resname_of = {int(r): str(p.resnames[np.flatnonzero(p.resnums == r)[0]]) for r in set(p.resnums.tolist())}
+    out = []
+    for b in range(0, len(plan.start), 2):
+        d = b // 2
+        if plan.cyx_partner[d] == -2:  # merged into its disulfide partner's fragment
+            out.append(np.zeros(0, dtype=np.int64))
+            continue
+        if plan.tmpl_slot is not None:
+            out.append(np.asarray(plan.tmpl_slot[plan.start[b]:plan.end[b]], dtype=np.int64))
+            continue
+        t = tables[TOPOLOGY_OF[resname_of[d + 2]]]
+        if plan.cyx_partner[d] >= 0:
+            # CYX pair: one 44-atom AMBER topology = two ACE-CYX-NME halves bridged by the S-S bond
+            # (utils/reference.py:41,71; distancefrag.py:185-240); halves in the order (this, partner)
+            half = t["natom"] // 2
+            nm = t["atom_names"]
+            out.append(np.concatenate([template_index_of_dipeptide(p, plan, d, nm[:half]),
+                                       half + template_index_of_dipeptide(p, plan, int(plan.cyx_partner[d]), nm[half:])]))
+        else:
+            out.append(template_index_of_dipeptide(p, plan, d, t["atom_names"]))
+    return out
+
+
+def acenme_alias(plan: FragmentPlan) -> np.ndarray:
+    """int64 [Nf]: for every ACE-NME row the dipeptide row that carries the same atom (-1 on dipeptide rows).
+    ACE-NME k = acetyl-like part of dipeptide k+1 + N-methyl-amide-like part of dipeptide k (distancefrag.py:291-302)."""
+    alias = -np.ones(len(plan.z), dtype=np.int64)
+    for b in range(1, len(plan.start), 2):
+        k = b // 2
+        rows = np.arange(plan.start[b], plan.end[b])
+        dn = np.arange(plan.dip_row_start[k + 1], plan.dip_row_end[k + 1])  # dipeptide k+1
+        dp = np.arange(plan.dip_row_start[k], plan.dip_row_end[k])          # dipeptide k
+
+        def key(rw):
+            return (int(plan.src[rw]), int(plan.acceptor[rw]), int(plan.toward[rw]))
+
+        lut_n = {key(rw): rw for rw in dn}
+        lut_p = {key(rw): rw for rw in dp}
+        for j, rw in enumerate(rows):  # rows 0..5: acetyl-like part, 6..11: amide-like part (both row orders)
+            alias[rw] = (lut_n if j < 6 else lut_p)[key(rw)]
+    return alias
+
+
 def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> HydrogenPlan:
     Nf = len(plan.z)
     B = len(plan.start)
@@ -134,22 +181,14 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
     def add_occ(row, typ, term, end, ncap):
         occ.setdefault(int(row), []).append((typ, term, end, ncap))
 
+    slots = template_slots(p, plan, tables)
     for b in range(0, B, 2):
         d = b // 2
+        ti = slots[d]
         if plan.cyx_partner[d] == -2:  # merged into its disulfide partner's fragment
-            tmpl_index.append(np.zeros(0, dtype=np.int64))
+            tmpl_index.append(ti)
             continue
-        code = TOPOLOGY_OF[resname_of[d + 2]]
-        t = tables[code]
-        if plan.cyx_partner[d] >= 0:
-            # CYX pair: one 44-atom AMBER topology = two ACE-CYX-NME halves bridged by the S-S bond
-            # (utils/reference.py:41,71; distancefrag.py:185-240); halves in the order (this, partner)
-            half = t["natom"] // 2
-            nm = t["atom_names"]
-            ti = np.concatenate([template_index_of_dipeptide(p, plan, d, nm[:half]),
-                                 half + template_index_of_dipeptide(p, plan, int(plan.cyx_partner[d]), nm[half:])])
-        else:
-            ti = template_index_of_dipeptide(p, plan, d, t["atom_names"])
+        t = tables[TOPOLOGY_OF[resname_of[d + 2]]]
         tmpl_index.append(ti)
         rows = np.arange(plan.start[b], plan.end[b])
         assert len(rows) == len(ti)
@@ -225,22 +264,7 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
             ot.append(typ); oterm.append(term); oend.append(end); ow.append(1.0 / n)
         occ_ptr.append(len(ot))
 
-    # ACE-NME rows alias the dipeptide rows they are cut from
-    alias = -np.ones(Nf, dtype=np.int64)
-    for b in range(1, B, 2):
-        k = b // 2  # ACE-NME k: acetyl part of dipeptide k+1 (its first-residue rows), amide part of dipeptide k
-        rows = np.arange(plan.start[b], plan.end[b])
-        dn = np.arange(plan.dip_row_start[k + 1], plan.dip_row_end[k + 1])  # dipeptide k+1
-        dp = np.arange(plan.dip_row_start[k], plan.dip_row_end[k])          # dipeptide k
-
-        def key(rw):
-            return (int(plan.src[rw]), int(plan.acceptor[rw]), int(plan.toward[rw]))
-
-        lut_n = {key(rw): rw for rw in dn}
-        lut_p = {key(rw): rw for rw in dp}
-        for j, rw in enumerate(rows):
-            lut = lut_n if j < 6 else lut_p
-            alias[rw] = lut[key(rw)]
+    alias = acenme_alias(plan)  # ACE-NME rows alias the dipeptide rows they are cut from
 
     index_keys = ("i", "j", "k", "l")  # atom rows; every other key is a float parameter (force constants: "kf")
     f32 = lambda d_: {k_: np.asarray(v, dtype=np.int32 if k_ in index_keys else np.float32) for k_, v in d_.items()}
@@ -255,29 +279,34 @@ def build_hydrogen_plan(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Hy
 def amber_ordered(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> FragmentPlan:
     """The same plan with the rows of every fragment in the REFERENCE's order: dipeptides in the atom order of their
     AMBER topology (what utils/seq_dict.pkl produces, distancefrag.py:728-737), ACE-NME fragments as the first six
-    atoms of the next dipeptide followed by the last six of the previous one (distancefrag.py:291-302).  A
-    FragmentData built from it is row for row what `DistanceFragment.get_fragments` returns
-    (tests/test_fragmentation_and_sharding.py, against the reference's own fragmenter)."""
+    atoms of the next dipeptide followed by the last six of the previous one (distancefrag.py:291-302), and the
+    recombination pairs listed like the reference lists them (fragment by fragment, protein atoms ascending,
+    distancefrag.py:338-350,740-802).  A FragmentData built from it is row for row what
+    `DistanceFragment.get_fragments` returns (tests/test_fragmentation_and_sharding.py, against the reference's own
+    fragmenter).  This is what `fragmentation.build_plan` returns by default."""
     import dataclasses
 
-    hp = build_hydrogen_plan(p, plan, tables)
+    if plan.tmpl_slot is not None:
+        return plan
+    slots = template_slots(p, plan, tables)
+    alias = acenme_alias(plan)
     Nf = len(plan.z)
     new_of_old = np.arange(Nf, dtype=np.int64)
-    slot_in_dip = {}
+    tmpl_slot = -np.ones(Nf, dtype=np.int64)
     for b in range(0, len(plan.start), 2):
-        a0, ti = int(plan.start[b]), hp.tmpl_index[b // 2]
+        a0, ti = int(plan.start[b]), slots[b // 2]
         if len(ti):
             new_of_old[a0:a0 + len(ti)] = a0 + ti
-    n_dip = len(plan.dip_row_start)
+            tmpl_slot[a0:a0 + len(ti)] = np.arange(len(ti))
     nat_of = plan.dip_row_end - plan.dip_row_start
     for b in range(1, len(plan.start), 2):
         a0 = int(plan.start[b])
         for j in range(12):
-            src_row = int(hp.alias[a0 + j])              # the dipeptide row this ACE-NME row is a copy of
+            src_row = int(alias[a0 + j])              # the dipeptide row this ACE-NME row is a copy of
             d = int(np.flatnonzero((plan.dip_row_start <= src_row) & (src_row < plan.dip_row_end))[0])
             # template slot of that row inside ITS dipeptide half (CYX pairs: second half is offset by 22)
             frag = 2 * (d if plan.cyx_partner[d] != -2 else int(np.flatnonzero(plan.cyx_partner == d)[0]))
-            slot = int(hp.tmpl_index[frag // 2][src_row - int(plan.start[frag])])
+            slot = int(slots[frag // 2][src_row - int(plan.start[frag])])
             half0 = 0 if plan.cyx_partner[d] != -2 else int(nat_of[frag // 2])
             slot -= half0
             new_of_old[a0 + j] = a0 + (slot if j < 6 else 6 + slot - (int(nat_of[d]) - 6))
@@ -288,10 +317,18 @@ def amber_ordered(p: ProteinAtoms, plan: FragmentPlan, tables: dict) -> Fragment
     is_dip_row = np.repeat(plan.is_dipeptide, plan.end - plan.start)
     rows = np.arange(Nf)
     row_of_cat = np.concatenate([rows[is_dip_row], rows[~is_dip_row]]).astype(np.int64)
-    keep = fields["src"][row_of_cat] >= 0
+    cat_src = fields["src"][row_of_cat]
+    frag_of_cat = np.repeat(np.arange(len(plan.start)), plan.end - plan.start)[row_of_cat]
+    sel = np.flatnonzero(cat_src >= 0)
+    # fragment order of cat[...] first, protein atom second (a protein atom occurs once per fragment, except the atoms
+    # the two halves of a CYX pair share: those keep their row order)
+    cat_pos_of_frag = np.empty(len(plan.start), dtype=np.int64)
+    cat_pos_of_frag[np.concatenate([np.flatnonzero(plan.is_dipeptide), np.flatnonzero(~plan.is_dipeptide)])] = \
+        np.arange(len(plan.start))
+    sel = sel[np.lexsort((sel, cat_src[sel], cat_pos_of_frag[frag_of_cat[sel]]))]
     # original dipeptide row ranges move with their rows only through the in-fragment permutation (ranges unchanged)
-    return dataclasses.replace(plan, **fields, row_of_cat=row_of_cat, select_index=np.flatnonzero(keep).astype(np.int64),
-                               origin_index=fields["src"][row_of_cat][keep].astype(np.int64))
+    return dataclasses.replace(plan, **fields, row_of_cat=row_of_cat, select_index=sel.astype(np.int64),
+                               origin_index=cat_src[sel].astype(np.int64), tmpl_slot=tmpl_slot)
 
 
 class HydrogenRelaxer:

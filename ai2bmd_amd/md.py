@@ -111,10 +111,20 @@ class _MDBase:
         self.set_constraints(keep)
 
 
+def _draw(rng, n, device):
+    """(xi, eta) of one step from a caller-supplied source with numpy's `standard_normal(size)` (the reference hands
+    ASE `rng=RNGPool(seed, (n, 3), count=2)`, simulator.py:108; ASE draws xi, then eta)"""
+    xi = np.asarray(rng.standard_normal(size=(n, 3)), dtype=np.float32)
+    eta = np.asarray(rng.standard_normal(size=(n, 3)), dtype=np.float32)
+    return torch.as_tensor(xi, device=device), torch.as_tensor(eta, device=device)
+
+
 class Langevin(_MDBase):
     def __init__(self, numbers, positions, force_fn, device, timestep_fs=1.0, temperature_K=300.0,
-                 friction_per_fs=0.001, seed=0, tether_k=0.0):
+                 friction_per_fs=0.001, seed=0, tether_k=0.0, rng=None, velocities=None):
         """force_fn(pos[n,3] device tensor) -> (E 0-d tensor, F[n,3] tensor).
+        rng: object with numpy's `standard_normal(size=(n, 3))` supplying the two draws of every step (the reference's
+        RNGPool); velocities: start velocities [n,3] in ASE units instead of the built-in Maxwell-Boltzmann draw.
         tether_k > 0 restrains every atom to its start position (eV/A^2, threshold 0) - the reference's
         pre-equilibration device (simulator.py:139-166); bench.py uses it because seeded random weights are not a
         physical potential.  self.E / self.F are model + restraints (what ASE's atoms.get_forces() returns with
@@ -140,8 +150,12 @@ class Langevin(_MDBase):
         self.c4 = fr / 2.0 * self.c5
         self.gen = torch.Generator(device=device)
         self.gen.manual_seed(seed)
+        self.rng = rng
         # Maxwell-Boltzmann start (simulator.py:96)
-        self.v = torch.randn(self.n, 3, generator=self.gen, device=device) * torch.sqrt(T / self.m)
+        if velocities is not None:
+            self.v = torch.as_tensor(np.asarray(velocities), dtype=torch.float32, device=device).contiguous()
+        else:
+            self.v = torch.randn(self.n, 3, generator=self.gen, device=device) * torch.sqrt(T / self.m)
         self._init_observers(temperature_K)
         self.E, self.F = self._forces()
         self.steps = 0
@@ -165,8 +179,11 @@ class Langevin(_MDBase):
         return E + self.E_restraint, F
 
     def step(self):
-        xi = torch.randn(self.n, 3, generator=self.gen, device=self.device)
-        eta = torch.randn(self.n, 3, generator=self.gen, device=self.device)
+        if self.rng is not None:
+            xi, eta = _draw(self.rng, self.n, self.device)
+        else:
+            xi = torch.randn(self.n, 3, generator=self.gen, device=self.device)
+            eta = torch.randn(self.n, 3, generator=self.gen, device=self.device)
         rnd_pos = self.c5 * eta
         rnd_vel = self.c3 * xi - self.c4 * eta
         rnd_pos = rnd_pos - rnd_pos.sum(0, keepdim=True) / self.n  # fixcm
@@ -204,7 +221,10 @@ class LangevinHIP(_MDBase):
     - bitwise the same trajectory - in two launches fewer per step.  Any other `force_fn` is called as is."""
 
     def __init__(self, numbers, positions, force_fn, device, timestep_fs=1.0, temperature_K=300.0,
-                 friction_per_fs=0.001, seed=0, tether_k=0.0, inplace_forces=True, fuse_tail=True):
+                 friction_per_fs=0.001, seed=0, tether_k=0.0, inplace_forces=True, fuse_tail=True, rng=None,
+                 velocities=None):
+        """rng / velocities: as in `Langevin` - with `rng` the two draws of every step are uploaded and the first half
+        reads them instead of its counter-based generator (`vsn_md_set_noise`)."""
         import ctypes as C
 
         from . import capi
@@ -232,7 +252,17 @@ class LangevinHIP(_MDBase):
             raise RuntimeError(f"vsn_md_create failed ({rc})")
         gen = torch.Generator(device=device)
         gen.manual_seed(seed)
-        self.v = (torch.randn(self.n, 3, generator=gen, device=device) * torch.sqrt(kT / self.m)).contiguous()
+        if velocities is not None:
+            self.v = torch.as_tensor(np.asarray(velocities), dtype=torch.float32, device=device).contiguous()
+        else:
+            self.v = (torch.randn(self.n, 3, generator=gen, device=device) * torch.sqrt(kT / self.m)).contiguous()
+        self.rng = rng
+        if rng is not None:
+            self._noise = torch.empty(2, self.n, 3, dtype=torch.float32, device=device)
+            rc = self._L.vsn_md_set_noise(self._h, C.c_void_p(self._noise[0].data_ptr()),
+                                          C.c_void_p(self._noise[1].data_ptr()))
+            if rc:
+                raise RuntimeError(f"vsn_md_set_noise failed ({rc})")
         self._obs = torch.zeros(4, dtype=torch.float32, device=device)
         self._init_observers(temperature_K)
         self._start_forces()
@@ -298,10 +328,16 @@ class LangevinHIP(_MDBase):
             raise RuntimeError(f"vsn_md_set_restraints failed ({rc})")
         self._start_forces()  # forces of the current geometry under the new restraint set
 
+    def _upload_noise(self):
+        xi, eta = _draw(self.rng, self.n, "cpu")
+        self._noise.copy_(torch.stack([xi, eta]))  # stream-ordered: lands before the first half reads it
+
     def _step_fused(self):
         """half1 + fragment gather | local evaluation + exchange | combine + half2"""
         C = self._C
         st = self._stream()
+        if self.rng is not None:
+            self._upload_noise()
         fp, cp, frag_pos, F_prot, E_tot = self._ff.fused_tail
         rc = self._L.vsn_md_half1_build(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
                                         C.c_void_p(self.F.data_ptr()), fp, C.c_void_p(frag_pos.data_ptr()), st)
@@ -321,6 +357,8 @@ class LangevinHIP(_MDBase):
             return self._step_fused()
         C = self._C
         st = self._stream()
+        if self.rng is not None:
+            self._upload_noise()
         rc = self._L.vsn_md_half1(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
                                   C.c_void_p(self.F.data_ptr()), st)
         if rc:

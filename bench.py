@@ -310,9 +310,11 @@ HBM_SUSTAINED_GBPS = 6300.0        # measured: a float4 device copy
 
 
 def step_bound(eng, nprof):
-    """sum over the instrumented launches of one step of max(flop / 116 TFLOP/s, algorithmic bytes / 6.3 TB/s) - what
-    the step would take with every GEMM launch at the sustained fp32 matrix rate and every node walk at the sustained
-    HBM rate - beside the time those launches actually took (the once-per-step launches - graph build, embeddings,
+    """what the step would take with every GEMM launch at the sustained fp32 matrix rate and every node walk at the
+    sustained HBM rate: per GEMM kernel kind, launches x max(average flop / 116 TFLOP/s, average algorithmic bytes /
+    6.3 TB/s) (averages over the launches of the kind: launches of one kind with different members make this a lower
+    bound of the per-launch sum), plus the node walks' algorithmic bytes / 6.3 TB/s - beside the time those launches
+    actually took (the once-per-step launches - graph build, embeddings,
     read-out, cap-hydrogen relaxation, integrator: ~20 launches at the 5-9 us floor of a dependent kernel - are neither
     in the bound nor in `covered_ms`)."""
     prof = eng.profile_read()
@@ -330,7 +332,8 @@ def step_bound(eng, nprof):
             bound += (v["bytes"] / (HBM_SUSTAINED_GBPS * 1e9)) * 1e3
             meas += v["ms"]
     return dict(step_bound_ms=bound / nprof, covered_ms=meas / nprof,
-                rule="sum over GEMM and node-walk launches of max(flop / 116 TFLOP/s, bytes / 6.3 TB/s)")
+                rule="per GEMM kernel kind: launches x max(avg flop / 116 TFLOP/s, avg bytes / 6.3 TB/s); "
+                     "node walks: algorithmic bytes / 6.3 TB/s")
 
 
 def rocprof_from_profile(workload, kernel):

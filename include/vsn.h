@@ -114,6 +114,14 @@ int vsn_profile_read_scatter(vsn_handle h, double* out8);
  * carries two events on its own dispatch packet (begin..end timestamps, no bracket correction).  Writes
  * min(max_kinds, 6) rows of 4 doubles {launches, total ms, total algorithmic bytes, 0}; returns the rows written. */
 int vsn_profile_read_walks(vsn_handle h, double* out, int max_kinds);
+/* THE byte model behind the figures above (and behind tools/walk_table.py, which calls it through ctypes instead of
+ * restating it): algorithmic HBM bytes of ONE launch of node walk `kernel` ("k_edge_attn", "k_edge_attn_update",
+ * "k_edge_update", "k_node_update", "k_bwd_hf1", "k_bwd_hf2", "k_bwd_attn_S", "k_bwd_norm_update", "k_bwd_gm_fused",
+ * "k_bwd_gf_fused", "k_bwd_edge_update_T", "k_bwd_edge_update_S", "k_bwd_vecmsg_S") over n nodes and e edges at hidden
+ * width H, S spherical components, nh heads - every distinct array the launch reads or writes, once.  f0 / f1: the
+ * launch's variant flags (csrc/engine.hip).  Pure function, no device; < 0 for an unknown kernel name.
+ * (the reference has no counterpart: it reads times off a profiler and never prices a launch against a roofline) */
+double vsn_walk_alg_bytes(const char* kernel, int H, int S, int nh, double n, double e, int f0, int f1);
 /* Average time (ms) between the two events of an EMPTY bracket on the launch stream, measured in the same profiled
  * calls (8 per chunk): what the bracket itself adds to every per-launch figure above.  0 when nothing was measured. */
 double vsn_profile_bracket_ms(vsn_handle h);
@@ -181,6 +189,12 @@ int vsn_md_create(vsn_md_handle* out, int device_id, int64_t n_atoms, const floa
 void vsn_md_destroy(vsn_md_handle p);
 int vsn_md_half1(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, void* stream);
 int vsn_md_half2(vsn_md_handle p, const float* dev_x, float* dev_v, float* dev_F, void* stream);
+/* The normal draws of the following first halves come from the caller instead of the built-in counter-based generator:
+ * dev_xi, dev_eta f32 [n_atoms,3] each (device, borrowed, re-read by every first half - rewrite them between steps), in
+ * the order ASE's Langevin.step draws them (xi, then eta).  The reference feeds ASE from its RNGPool of numpy normals
+ * (simulator.py:108 `rng=RNGPool(seed, (n, 3), count=2)`, utils/utils.py:28-49): a trajectory can only be laid beside
+ * ASE's on the same draws (tests/test_md_vs_ase.py).  (NULL, NULL) returns to the built-in generator. */
+int vsn_md_set_noise(vsn_md_handle p, const float* dev_xi, const float* dev_eta);
 /* The same two halves with the neighbouring launch of the force evaluation folded in (same arithmetic, same order,
  * bitwise the same trajectory; two launches fewer per step):
  *   vsn_md_half1_build    = vsn_md_half1, then vsn_build_fragments(plan) of the NEW positions into dev_frag_pos

@@ -323,59 +323,78 @@ def test_preprocessed_order_reproduces_the_reference_example():
 
 @pytest.mark.parametrize("name", ["chig", "chigcyx", "trpcage", "ww", "abd"])
 def test_plan_matches_reference_fragmenter(name):
-    """golden = the reference's own DistanceFragment.fragment + get_dipeptide_positions (oracle/ref_fragmenter.py) on
-    its pre-processed Chignolin example: same fragments, same atoms, same cap-hydrogen first-guess positions, same
-    force recombination (the reference's rows are in AMBER order, ours in residue order: matched by position).
-    "chigcyx" = the same protein with a fabricated CYX-CYX bridge (oracle/make_fragmenter_golden.py): the two
-    dipeptides are merged into one 44-atom fragment and the second slot stays empty."""
-    from ai2bmd_amd.fragmentation import build_plan, combine_host
+    """golden = the reference's own DistanceFragment.fragment + get_dipeptide_positions (oracle/ref_fragmenter.py).
+    The DEFAULT plan is the reference's fragment batch row for row, no permutation in between: atomic numbers,
+    fragment ranges, cap-hydrogen first-guess positions, select / origin indices - hence the same FragmentData and,
+    when `max_num_neighbors` truncates, the same lowest-index sources kept per target.
+    "chigcyx" = Chignolin with a fabricated CYX-CYX bridge (oracle/make_fragmenter_golden.py): the two dipeptides are
+    merged into one 44-atom fragment and the second slot stays empty."""
+    from ai2bmd_amd.fragment import FragmentData, make_batch_index
+    from ai2bmd_amd.fragmentation import build_plan, combine_host, fragment_positions
 
     prot = load_for_reference(name)
     plan = build_plan(prot)
     ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
-    assert np.array_equal(plan.start, ref["start"]) and np.array_equal(plan.end, ref["end"])
+    fd = FragmentData(plan.z, fragment_positions(plan, prot.positions).astype(np.float32), plan.start, plan.end,
+                      make_batch_index(plan.start, plan.end))
+    assert np.array_equal(fd.z, ref["z"])
+    assert np.array_equal(fd.start, ref["start"]) and np.array_equal(fd.end, ref["end"])
+    np.testing.assert_allclose(fd.pos, ref["pos"], atol=2e-5)
     assert plan.n_dip_rows == int(ref["n_dip_rows"])
-    perm = _row_permutation(plan, prot.positions, ref)          # also proves: same atoms and positions per fragment
-    assert sorted(perm.tolist()) == list(range(len(plan.z)))
-    # forces: random per-row forces in the REFERENCE's row order, recombined by the reference's rule
-    # (combiner.py:24-41 with the reference's select/origin indices) == ours on the permuted rows
-    rng = np.random.default_rng(0)
-    f_ref = rng.standard_normal((len(ref["z"]), 3))
+    assert np.array_equal(plan.select_index, ref["select_index"])
+    assert np.array_equal(plan.origin_index, ref["origin_index"])
     if name == "chigcyx":
         sizes = plan.end - plan.start
         assert sizes[2] == 44 and sizes[10] == 0 and plan.cyx_partner[1] == 5 and plan.cyx_partner[5] == -2
+    # the protein may come in ANY atom order (atoms are matched to template slots by name): same batch
+    shuffled = build_plan(load_protein(name))
+    assert np.array_equal(shuffled.z, plan.z) and np.array_equal(shuffled.start, plan.start)
+    # forces: random per-row forces recombined by the reference's rule (combiner.py:24-41 with the reference's
+    # select / origin indices) == combine_host on the plan
+    rng = np.random.default_rng(0)
+    f_ref = rng.standard_normal((len(ref["z"]), 3))
     is_dip = np.zeros(len(ref["z"]), bool)
     for b in range(0, len(ref["start"]), 2):
         is_dip[ref["start"][b]:ref["end"][b]] = True
     cat = np.concatenate([f_ref[is_dip], -f_ref[~is_dip]])[ref["select_index"]]
     F_ref = np.zeros((plan.n_prot, 3))
     np.add.at(F_ref, ref["origin_index"], cat)
-    f_mine = np.zeros_like(f_ref)
-    f_mine[perm] = f_ref
     n_nonempty = int(((plan.end - plan.start) > 0).sum())  # energies exist for non-empty fragments only
-    _, F_mine = combine_host(plan, np.zeros((n_nonempty, 1), np.float32), f_mine.astype(np.float32))
+    _, F_mine = combine_host(plan, np.zeros((n_nonempty, 1), np.float32), f_ref.astype(np.float32))
     np.testing.assert_allclose(F_mine, F_ref, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", ["chig", "chigcyx", "trpcage", "ww", "abd"])
-def test_amber_ordered_plan_is_row_identical_to_the_reference(name):
-    """ai2bmd_amd.hydrogen.amber_ordered: a FragmentData built from it equals, row for row, what the reference's
-    DistanceFragment produces - atomic numbers, first-guess positions, select/origin indices."""
-    from ai2bmd_amd.amber import load_tables
-    from ai2bmd_amd.fragmentation import build_plan, fragment_positions
-    from ai2bmd_amd.hydrogen import amber_ordered
+def test_grouped_layout_is_a_row_permutation_of_the_default(name):
+    """`order="grouped"` ([previous part | residue | next part], the layout the AMBER order is derived from) holds the
+    same atoms at the same places in every fragment and recombines to the same protein forces; building the hydrogen
+    plan from either gives the same terms."""
+    from ai2bmd_amd.amber import default_tables
+    from ai2bmd_amd.fragmentation import build_plan, combine_host, fragment_positions
+    from ai2bmd_amd.hydrogen import amber_ordered, build_hydrogen_plan
 
-    prot = load_for_reference(name)
-    plan = amber_ordered(prot, build_plan(prot), load_tables(os.path.join(GOLDEN, "amber_tables.npz")))
-    ref = np.load(os.path.join(GOLDEN, f"fragref_{name}.npz"))
-    assert np.array_equal(plan.z, ref["z"])
-    assert np.array_equal(plan.start, ref["start"]) and np.array_equal(plan.end, ref["end"])
-    np.testing.assert_allclose(fragment_positions(plan, prot.positions), ref["pos"], atol=2e-5)
-    # the recombination map {row of cat[F_dip, F_ace] -> protein atom} is the same set of pairs (the reference lists
-    # them in protein-atom order inside each fragment, we list them in row order)
-    o = np.argsort(ref["select_index"])
-    assert np.array_equal(plan.select_index, ref["select_index"][o])
-    assert np.array_equal(plan.origin_index, ref["origin_index"][o])
+    prot = load_protein(name)
+    plan, grouped = build_plan(prot), build_plan(prot, order="grouped")
+    assert grouped.tmpl_slot is None and plan.tmpl_slot is not None
+    ref = dict(z=plan.z, pos=fragment_positions(plan, prot.positions).astype(np.float32), start=plan.start, end=plan.end)
+    perm = _row_permutation(grouped, prot.positions, ref)   # grouped row of every default row
+    assert sorted(perm.tolist()) == list(range(len(plan.z)))
+    rng = np.random.default_rng(1)
+    f = rng.standard_normal((len(plan.z), 3)).astype(np.float32)
+    f_g = np.zeros_like(f)
+    f_g[perm] = f
+    n_nonempty = int(((plan.end - plan.start) > 0).sum())
+    e = np.zeros((n_nonempty, 1), np.float32)
+    np.testing.assert_allclose(combine_host(plan, e, f)[1], combine_host(grouped, e, f_g)[1], atol=1e-6)
+    again = amber_ordered(prot, plan, default_tables())
+    assert again is plan  # already ordered
+    h1, h2 = build_hydrogen_plan(prot, plan, default_tables()), build_hydrogen_plan(prot, grouped, default_tables())
+    assert len(h1.cap_rows) == len(h2.cap_rows) and len(h1.pair["i"]) == len(h2.pair["i"])
+    assert all(np.array_equal(t, np.arange(len(t))) for t in h1.tmpl_index)
+    assert np.array_equal(np.sort(perm[h1.cap_rows]), np.sort(h2.cap_rows))
+    for tab in ("bond", "angle", "dihedral"):
+        a, b = getattr(h1, tab), getattr(h2, tab)
+        assert np.array_equal(perm[a["i"]], b["i"]) and np.allclose(a["kf"], b["kf"])
 
 
 def test_edge_balanced_device_ranges_cover_and_balance():

@@ -195,3 +195,61 @@ def test_constant_force_tensor_is_never_written_with_inplace_forces_off(lib_buil
         md.step()
     torch.cuda.synchronize()
     assert torch.equal(cached, keep)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_injected_draws_hip_integrator_follows_the_torch_restatement_step_for_step(lib_built, fused):
+    """With noise: both integrators take the step's (xi, eta) from the SAME source - the reference's own RNGPool
+    (utils/utils.py:28-49, executed from the reference tree / oracle/_ref; simulator.py:108 hands it to ASE) - and the
+    same start velocities, so the trajectories can be compared step for step instead of statistically: the HIP
+    kernels (`vsn_md_set_noise` -> k_md_half1[_build] / k_md_[combine_]half2) against ~25 torch elementwise ops.
+    `fused`: through the fused ends on a real ShardedFragmentForces (Chignolin, H = 64) instead of a harmonic well.
+    (The same comparison against ase.md.langevin.Langevin itself is staged in tests/test_md_vs_ase.py.)"""
+    import os
+
+    from ai2bmd_amd.md import KB, MASSES, Hookean, Langevin, LangevinHIP
+    from oracle.ref_caller import caller_source, load_reference_caller
+
+    assert caller_source() is not None
+    utils = load_reference_caller(lambda *a: None, object).utils
+    if fused:
+        from ai2bmd_amd.bonded import ShardedFragmentForces
+        from ai2bmd_amd.fragmentation import ProteinAtoms, build_plan
+        from ai2bmd_amd.synthetic import default_hparams, make_state_dict
+        from ai2bmd_amd.visnet_calculator import ViSNetEngine
+        from conftest import GOLDEN
+
+        d = np.load(os.path.join(GOLDEN, "protein_chig.npz"))
+        prot = ProteinAtoms(d["names"], d["resnames"], d["resnums"], d["numbers"], d["positions"].astype(np.float64))
+        hp = default_hparams(embedding_dimension=64, num_layers=2)
+        eng = ViSNetEngine(hp, make_state_dict(hp, seed=9), "cuda:0")
+        numbers, pos = prot.numbers, prot.positions.astype(np.float32)
+        plan = build_plan(prot)
+        fa = ShardedFragmentForces.for_engine(eng, plan).step
+        fb = ShardedFragmentForces.for_engine(eng, plan).step
+    else:
+        rng = np.random.default_rng(0)
+        numbers = rng.choice([1, 6, 7, 8, 16], size=175)
+        pos = rng.standard_normal((175, 3)).astype(np.float32)
+        fa = fb = harmonic(2.0)
+    n = len(numbers)
+    m = np.array([MASSES[int(z)] for z in numbers])
+    v0 = np.random.default_rng(4).standard_normal((n, 3)) * np.sqrt(300.0 * KB / m)[:, None]
+    a = Langevin(numbers, pos, fa, "cuda:0", seed=1, tether_k=0.7, rng=utils.RNGPool(21, (n, 3), 2), velocities=v0)
+    b = LangevinHIP(numbers, pos, fb, "cuda:0", seed=1, tether_k=0.7, rng=utils.RNGPool(21, (n, 3), 2), velocities=v0,
+                    inplace_forces=fused)
+    assert (b._ff is not None) == fused
+    cons = [Hookean(0, 5, 3.0, rt=1.0)]
+    a.set_constraints(cons)
+    b.set_constraints(cons)
+    for k in range(40):
+        a.step()
+        b.step()
+        np.testing.assert_allclose(b.x.cpu().numpy(), a.x.cpu().numpy(), rtol=0, atol=2e-5, err_msg=f"x, step {k}")
+        np.testing.assert_allclose(b.v.cpu().numpy(), a.v.cpu().numpy(), rtol=0, atol=2e-5, err_msg=f"v, step {k}")
+    # the draws really entered: the same run on the built-in generator differs
+    c = LangevinHIP(numbers, pos, fb, "cuda:0", seed=1, tether_k=0.7, velocities=v0, inplace_forces=fused)
+    c.set_constraints(cons)
+    for _ in range(40):
+        c.step()
+    assert np.abs(c.x.cpu().numpy() - b.x.cpu().numpy()).max() > 1e-3

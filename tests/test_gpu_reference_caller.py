@@ -129,7 +129,39 @@ def test_reference_caller_against_the_all_reference_chain_golden(ckpt_dir):
     # no worse than 4x the reference's own fp32 error on this chain
     ref_err = max(np.abs(g["Fprot32"] - Fg).max(), 2e-6)
     assert np.abs(F - Fg).max() <= 4 * ref_err + 1e-6 * np.abs(Fg).max()
-    # the recombination indices our fragment producer leaves are what the reference's leaves: torch, default device
+    # the recombination indices our fragment producer leaves are what the reference's leaves: torch, default device,
+    # the same values in the same order; and the fragment batch is the reference's row for row
     assert torch.is_tensor(prot.select_index) and prot.select_index.device.type == "cuda"
-    assert len(prot.select_index) == len(g["select_index"]) and len(prot.origin_index) == len(g["origin_index"])
-    assert np.array_equal(np.sort(prot.origin_index.cpu().numpy()), np.sort(g["origin_index"]))
+    assert np.array_equal(prot.select_index.cpu().numpy(), g["select_index"])
+    assert np.array_equal(prot.origin_index.cpu().numpy(), g["origin_index"])
+    assert np.array_equal(prot.fragments_z, g["z"]) and np.array_equal(prot.fragments_start, g["start"])
+
+
+@pytest.mark.parametrize("case,name", [("chig_nb20", "chig"), ("abd_nb31", "abd"), ("abd_nb24", "abd")])
+def test_reference_caller_under_neighbour_truncation(lib_built, tmp_path, case, name):
+    """tests/golden/refchain_<case>.npz: the all-reference chain with `max_num_neighbors` lowered until targets
+    truncate (Chignolin at 20: 30 % of the targets; ABD at 31 and 24).  `radius_graph` keeps the lowest-index sources,
+    so the result depends on the row order of the FragmentData: the reference's DLBondedCalculator on the HIP seam, fed
+    by the HIP fragment producer (rows in the reference's AMBER order), reproduces it."""
+    from ai2bmd_amd.fragmentation import preprocessed_order
+    from ai2bmd_amd.synthetic import default_hparams, make_state_dict, write_lightning_ckpt
+
+    g = np.load(os.path.join(GOLDEN, f"refchain_{case}.npz"))
+    hp = default_hparams(max_num_neighbors=int(g["max_num_neighbors"]))
+    write_lightning_ckpt(str(tmp_path / "visnet-uni-bench.ckpt"), hp, make_state_dict(hp, seed=int(g["weight_seed"])))
+    ref, DS, calls = _reference_caller(relax=False, handles="separate")
+    calc = ref.DLBondedCalculator(str(tmp_path), "bench")
+    prot = _protein(name)
+    if name != "chig":
+        prot = preprocessed_order(prot)  # the atom numbering of the golden's protein forces
+    calc.fragment_method.fragment(prot)
+    assert np.array_equal(prot.fragments_z, g["z"]) and np.array_equal(prot.fragments_end, g["end"])
+    DS.set_work_partitions(prot.fragments_start.tolist(), prot.fragments_end.tolist())
+    E, F = calc(prot)
+    assert len(calls) == len(DS.get_work_partitions()) and int(g["n_truncated"]) >= 1
+    Fg, Eg = g["Fprot64"], float(g["Eprot64"])
+    assert np.abs(F - Fg).max() <= 1e-4 * max(1.0, np.abs(Fg).max()), np.abs(F - Fg).max()
+    assert np.abs(F - Fg).mean() <= 1e-5 * max(1.0, np.abs(Fg).mean())
+    assert abs(float(E) - Eg) <= 1e-4 * max(1.0, abs(Eg))
+    ref_err = max(np.abs(g["Fprot32"] - Fg).max(), 2e-6)
+    assert np.abs(F - Fg).max() <= 4 * ref_err + 1e-6 * np.abs(Fg).max()

@@ -18,7 +18,7 @@ def test_oracle_matches_reference_on_protein_batches(name, tag):
     hp = json.loads(str(d["hparams"]))
     sd = make_state_dict(hp, seed=int(d["weight_seed"]))
     E, F, c = ViSNetOracle(hp, sd, torch.float64).energy_forces(d["z"], d[f"pos_{tag}"], d["start"], d["end"])
-    assert np.diff(c["graph"]["rowptr"]).max() == int(d[f"max_degree_{tag}"]) <= hp["max_num_neighbors"]
+    assert np.diff(c["graph"]["rowptr"]).max() == min(int(d[f"max_degree_{tag}"]), hp["max_num_neighbors"])
     np.testing.assert_allclose(E, d[f"E_ref64_{tag}"], rtol=0, atol=1e-9 * max(1.0, np.abs(d[f"E_ref64_{tag}"]).max()))
     np.testing.assert_allclose(F, d[f"F_ref64_{tag}"], rtol=0, atol=1e-9 * max(1.0, np.abs(d[f"F_ref64_{tag}"]).max()))
 
@@ -52,10 +52,9 @@ def test_builder_chain_golden_equals_the_all_reference_chain():
     assert int(a["weight_seed"]) == int(b["weight_seed"])
     assert abs(float(a["Eprot64"]) - float(b["Eprot64_placed"])) < 1e-10
     assert np.abs(a["Fprot64"] - b["Fprot64_placed"]).max() < 1e-12
-    # the reference's rows are in AMBER order, ours in residue order: same multiset of atoms per fragment
+    # the same fragment batch row for row (our plan emits the reference's AMBER row order)
     assert np.array_equal(a["start"], b["start"]) and np.array_equal(a["end"], b["end"])
-    for s, e in zip(a["start"], a["end"]):
-        assert sorted(a["z"][s:e].tolist()) == sorted(b["z"][s:e].tolist())
+    assert np.array_equal(a["z"], b["z"]) and np.abs(a["pos"] - b["pos_placed"]).max() < 2e-5
     # the fp32 run of the same all-reference chain: the error floor the HIP path is compared with
     assert np.abs(a["Fprot32"] - a["Fprot64"]).max() < 1e-5
 

@@ -3,8 +3,9 @@
     python tools/walk_table.py <tag>        (reads profiles/<tag>_*; run after tools/profile_round.sh on the same build)
 
 Per kernel: launches per step / batch, average duration from the rocprofv3 KERNEL TRACE, ALGORITHMIC bytes per launch
-(every distinct array the launch reads or writes, once: the formulas below = the ones csrc/engine.hip evaluates for
-the live figures of bench.py), the counter bytes per launch (2 FETCH_SIZE + WRITE_SIZE, separate PMC passes), their
+(every distinct array the launch reads or writes, once: `vsn_walk_alg_bytes` of csrc/engine.hip, the same function the
+live figures of bench.py come from; where the bench record of the round holds the live per-launch average of a walk -
+launch variants mixed as they occur in a step - that figure is used), the counter bytes per launch (2 FETCH_SIZE + WRITE_SIZE, separate PMC passes), their
 ratio, the achieved rate on algorithmic bytes against 8 TB/s, and the launch's bound at the sustained 6.3 TB/s.
 `step_bound_ms` = sum over the GEMM launches of flop / 116 TFLOP/s + over these launches of bytes / 6.3 TB/s.
 """
@@ -20,36 +21,18 @@ H, S, NH = 256, 8, 8
 HBM_PEAK, HBM_SUST, MFMA_SUST = 8000e9, 6300e9, 116e12
 
 
-def alg_floats(kernel, n, e, **f):
-    """distinct floats (4-byte indices counted as floats) one launch touches; n nodes, e edges of the launch"""
-    if kernel == "k_edge_attn_update":
-        return e * (2 * H + 2 + H) + n * (3 * H + H + 1) + e * (3 * H + 8) + n * S * 2 * H
-    if kernel == "k_edge_attn":
-        return e * (2 * H + 2 + H) + n * (3 * H + H + 1)
-    if kernel == "k_edge_update":  # pe[f], f r/w, d, src | vp[wt|ws]
-        return e * (3 * H + 8 + 1) + n * S * 2 * H
-    if kernel == "k_node_update":
-        return e * (2 * H + 8 + 1) + n * (S * H * 6 + 3 * H + 2 * H + 1) + n * (2 * H + 1 + S * H)
-    if kernel == "k_bwd_hf1":  # with the edge update (7 of its 8 launches per step)
-        return e * (2 * H + 8 + 3 + 2 * S + 2 * H) + n * (3 * S * H + 2) + e * (2 * H + 2 * S + H) + n * 3 * S * H
-    if kernel == "k_bwd_hf2":
-        return (e * (2 * H + 2 * H + 1 + 2 + 1 + H + 2 * H + 2 * NH) + n * (3 * H + 3 * H + H + 2)
-                + e * (2 * H + 8) + n * 2 * S * H)
-    if kernel == "k_bwd_attn_S":
-        return e * (3 * H + 2 * NH + 2) + n * (3 * H + 1)
-    if kernel == "k_bwd_norm_update":
-        return n * (2 * H + 1 + 2 * H + S * H + 3 * S * H + H + S * H + 3 * S * H + 3 * H) + n * (H + S * H)
-    if kernel == "k_bwd_gm_fused":  # tpre, d, g_geo r/w, src|tgt | vh, g_vec; write g_m
-        return e * (2 * H + 8 + 2 * S + 2 + H) + n * 2 * S * H
-    if kernel == "k_bwd_gf_fused":  # pe[dk|dv], g_m r/w, g_pe[f], C, g_geo r/w, ids, sat_tmp, g_f r/w | qkv, g_A
-        return e * (2 * H + 2 * H + H + 1 + 2 + 2 + 2 * NH + 2 * H) + n * 4 * H
-    if kernel == "k_bwd_edge_update_T":
-        return e * (3 * H + 8 + 4 * S + 1) + n * 3 * S * H
-    if kernel == "k_bwd_edge_update_S":
-        return e * (2 * H + 10) + n * 2 * S * H
-    if kernel == "k_bwd_vecmsg_S":
-        return e * (H + 2) + n * 2 * S * H
-    return None
+def alg_floats(kernel, n, e, f0=1, f1=0):
+    """distinct floats one launch touches = vsn_walk_alg_bytes / 4: the byte model lives in csrc/engine.hip ONLY (the
+    live figures of bench.py come from the same function); this is a ctypes call, not a restatement.  Default flags =
+    the common launch of a Chignolin step (next-layer LayerNorm fused, edge update present, accumulating adjoint);
+    k_bwd_hf2 sums 2 K-slices of g_m and 3 of g_A there."""
+    sys.path.insert(0, ROOT)
+    from ai2bmd_amd import capi
+
+    if kernel == "k_bwd_hf2" and f1 == 0:
+        f0, f1 = 2, 3
+    by = capi.lib().vsn_walk_alg_bytes(kernel.encode(), H, S, NH, float(n), float(e), int(f0), int(f1))
+    return None if by < 0 else by / 4.0
 
 
 def load_csv(path):
@@ -82,7 +65,10 @@ def pmc_bytes(rows, name):
     return None
 
 
-def table(tag, wl, n, e, per, kernels, launches_of):
+def table(tag, wl, n, e, per, kernels, launches_of, live=None):
+    """live: {kernel: algorithmic MB per launch} as the engine reported them in the bench run of this round (launch
+    variants averaged as they occur in a step); used where present so that profiles/ and the bench line agree"""
+    live = live or {}
     ks = load_csv(os.path.join(ROOT, "profiles", f"{tag}_{wl}_kernel_stats.csv"))
     pm = load_csv(os.path.join(ROOT, "profiles", f"{tag}_{wl}_pmc.csv"))
     out = [f"| kernel | launches per {per} | avg µs (trace) | algorithmic MB | counter MB | counter / algorithmic | "
@@ -94,8 +80,7 @@ def table(tag, wl, n, e, per, kernels, launches_of):
             continue
         calls, avg_ns = p
         lp = launches_of(k)
-        fl = alg_floats(k, n / lp["chunks"], e / lp["chunks"])
-        by = 4.0 * fl
+        by = live[k] * 1e6 if k in live else 4.0 * alg_floats(k, n / lp["chunks"], e / lp["chunks"])
         cb = pmc_bytes(pm, k)
         rate = by / (avg_ns * 1e-9)
         bound_us = by / HBM_SUST * 1e6
@@ -127,7 +112,14 @@ def main():
              "`tools/profile_round.sh`).  Algorithmic bytes = every distinct array of the launch once "
              "(`csrc/engine.hip`, `tools/walk_table.py::alg_floats`).", "",
              f"## Chignolin MD step (N = {n} fragment atoms, E = {e} edges, H = 256, L = 9)", ""]
-    t, meas, bound = table(tag, "chig_md", n, e, "step", list(chig), lambda k: dict(per=chig[k], chunks=1))
+    live = {}
+    if gemm:
+        for k, v in (gemm.get("reverse_walks") or {}).items():
+            live[k] = v["alg_MB"]
+        for k, v in ((gemm.get("hbm") or {}).get("all_scatter_kernels") or {}).items():
+            live[k] = v["algorithmic_bytes_per_launch"] / 1e6
+        live.pop("k_edge_attn", None)  # (the live record pools k_edge_attn and k_edge_attn_update: the trace separates them)
+    t, meas, bound = table(tag, "chig_md", n, e, "step", list(chig), lambda k: dict(per=chig[k], chunks=1), live=live)
     lines += t
     lines += ["", f"Node walks: {meas:.0f} µs of the step measured, {bound:.0f} µs at 6.3 TB/s on algorithmic bytes."]
     if gemm:
