@@ -205,6 +205,84 @@ class _HipTail:
             raise RuntimeError(f"vsn_combine_with_energy failed ({rc})")
 
 
+class _DevView:
+    """zero-copy torch view of library-owned device memory (the CUDA array interface torch.as_tensor understands)"""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f4", data=(int(ptr), False), version=2)
+
+
+class P2PExchange:
+    """The tuned exchange step: every rank STORES its slot into its peers' gather buffers - one HIP
+    launch per step, no collective library in between (`vsn_p2p_*`, csrc/p2p.hip; buffers mapped into the peers with
+    hipIpcGetMemHandle / hipIpcOpenMemHandle, xGMI point-to-point).  The handle records are exchanged ONCE over the
+    process group that already exists (`all_gather_object`: gloo or RCCL); after that the group is not on the step's
+    path.  `send` is the rank's slot (its kernels write there), `gather(stream)` returns this step's [world * slot]
+    buffer - bitwise what `all_gather_into_tensor(recv, send)` would hold."""
+
+    def __init__(self, device, rank, world, slot, group=None):
+        self.L = capi.lib()
+        self.device, self.rank, self.world, self.slot, self.group = device, rank, world, int(slot), group
+        idx = torch.device(device).index or 0
+        self._h = C.c_void_p()
+        rc = self.L.vsn_p2p_create(C.byref(self._h), idx, rank, world, self.slot)
+        if rc:
+            raise RuntimeError(f"vsn_p2p_create failed ({rc})")
+        mine = (C.c_char * capi.P2P_HANDLE_BYTES)()
+        rc = self.L.vsn_p2p_export(self._h, C.cast(mine, C.c_void_p))
+        if rc:
+            raise RuntimeError(f"vsn_p2p_export failed ({rc}): hipIpcGetMemHandle refused (HSA_ENABLE_IPC_MODE_LEGACY=0?)")
+        records = [bytes(mine)]
+        if world > 1:
+            import torch.distributed as dist
+
+            records = [None] * world
+            dist.all_gather_object(records, bytes(mine), group=group)
+        blob = b"".join(records)
+        rc = self.L.vsn_p2p_connect(self._h, C.cast(C.c_char_p(blob), C.c_void_p))
+        if rc:
+            raise RuntimeError(f"vsn_p2p_connect failed ({rc}): hipIpcOpenMemHandle refused a peer's buffer")
+        self.send = torch.as_tensor(_DevView(self.L.vsn_p2p_send_buffer(self._h), self.slot), device=device)
+        self._bufs = [torch.as_tensor(_DevView(self.L.vsn_p2p_gather_buffer(self._h, k), world * self.slot), device=device)
+                      for k in (0, 1)]
+        self._step = 0
+        if world > 1:
+            dist.barrier(group=group)  # every rank has mapped every buffer before the first store
+
+    def gather(self, stream):
+        rc = self.L.vsn_p2p_allgather(self._h, C.c_void_p(stream.cuda_stream), None)
+        if rc:
+            raise RuntimeError(f"vsn_p2p_allgather failed ({rc})")
+        self._step += 1
+        return self._bufs[self._step & 1]
+
+    def check(self, stream=None):
+        """synchronises; raises if a wait gave up (a peer never stored its slot)"""
+        st = stream or torch.cuda.current_stream(self.device)
+        rc = self.L.vsn_p2p_status(self._h, C.c_void_p(st.cuda_stream))
+        if rc:
+            raise RuntimeError(f"P2P exchange: the wait of step {rc} timed out (a peer never delivered its slot)")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if self.world > 1:
+                import torch.distributed as dist
+
+                torch.cuda.synchronize(self.device)
+                if dist.is_initialized():
+                    dist.barrier(group=self.group)  # nobody frees a buffer a slower peer still stores into
+            self.L.vsn_p2p_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):  # (no collective from a finaliser: close() is the orderly way)
+                self.L.vsn_p2p_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class ShardedFragmentForces:
     """Device-resident protein -> (E, F[n_prot,3]) evaluator, one instance per rank.
 
@@ -245,6 +323,7 @@ class ShardedFragmentForces:
         self.direct = False  # True when local_fn writes straight into the exchange buffer
         self.emulate = False
         self.force_collective = False  # world == 1: still go through the all-gather (exercises RCCL on a 1-GPU box)
+        self.p2p = None                # P2PExchange: direct peer writes instead of the collective (for_engine exchange="p2p")
         self.fused_tail = None
         self.energy_sign = torch.as_tensor(plan.energy_sign, device=device)
         nonempty = (plan.end - plan.start) > 0
@@ -275,6 +354,8 @@ class ShardedFragmentForces:
         energies gathered -> the padded buffer the combine reads.  prebuilt: the fragment geometry of `prot_pos` is
         already in `self.frag_pos` (the integrator's fused first half wrote it: LangevinHIP, vsn_md_half1_build)."""
         e_loc, f_loc = self.local_fn(prot_pos, prebuilt) if prebuilt else self.local_fn(prot_pos)
+        if self.p2p is not None:  # the rank's kernels wrote its slot of the P2P send buffer: one launch gathers all slots
+            return self.p2p.gather(torch.cuda.current_stream(self.device))
         stage = self.recv if (self.world == 1 and not self.force_collective) else self.send
         if not self.direct:  # local_fn returned its own tensors: stage them into the exchange buffer
             stage[: self.local_rows * 3] = f_loc.reshape(-1)
@@ -292,15 +373,21 @@ class ShardedFragmentForces:
     # ---- product wiring: HIP engine + HIP gather/cap-H + HIP combine -------------------
     @classmethod
     def for_engine(cls, engine, plan: FragmentPlan, rank=0, world=1, group=None, hydrogen=None,
-                   force_collective=False, balance: str = "atoms", tail=None):
+                   force_collective=False, balance: str = "atoms", tail=None, exchange: str = "collective"):
         """hydrogen: optional ai2bmd_amd.hydrogen.HydrogenPlan - relax the cap hydrogens every call like
         DistanceFragment.get_fragments (distancefrag.py:76-82).  The relaxation couples all dipeptides, so with
         it every rank builds and relaxes ALL fragment rows and then evaluates only its own shard.
         tail: the device ends (default: the HIP kernels through the C ABI, `_HipTail`); the CPU tests pass a torch
-        stand-in together with a stand-in engine to run this very wiring over gloo."""
+        stand-in together with a stand-in engine to run this very wiring over gloo.
+        exchange: "collective" (default) = ONE `all_gather_into_tensor` per step (RCCL); "p2p" = the tuned variant,
+        every rank stores its slot straight into its peers' gather buffers (`P2PExchange`, one process per GPU)."""
         dev = engine.device
         self = cls(plan, rank, world, dev, group, balance=balance)
         self.force_collective = bool(force_collective)
+        if exchange not in ("collective", "p2p"):
+            raise ValueError(f"exchange must be 'collective' or 'p2p', not {exchange!r}")
+        if exchange == "p2p":
+            self.p2p = P2PExchange(dev, rank, world, self.slot, group)
         tail = tail or _HipTail(dev, engine.index)
         lo, hi = self.atom_lo[rank], self.atom_hi[rank]
         # fragment geometry plan restricted to this rank's rows (all rows when the caps are relaxed)
@@ -328,7 +415,7 @@ class ShardedFragmentForces:
         self.frag_pos = pos_geo
         nloc, bloc = hi - lo, self.f1 - self.f0
         # the kernels write this rank's forces / energies straight into its slot of the exchange buffer
-        stage = self.recv if (world == 1 and not force_collective) else self.send
+        stage = self.p2p.send if self.p2p is not None else (self.recv if (world == 1 and not force_collective) else self.send)
         f_loc = stage[: max(nloc, 1) * 3].view(-1, 3)
         e_loc = stage[self.max_rows * 3: self.max_rows * 3 + max(bloc, 1)]
         self.direct = True

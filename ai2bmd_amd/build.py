@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvsn_hip.so")
-SOURCES = ["gemm.hip", "graph.hip", "layer_fwd.hip", "layer_bwd.hip", "fused.hip", "vecnorm.hip", "head.hip", "head_fused.hip", "md.hip", "mm.hip", "hydrogen.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "graph.hip", "layer_fwd.hip", "layer_bwd.hip", "fused.hip", "vecnorm.hip", "head.hip", "head_fused.hip", "md.hip", "mm.hip", "hydrogen.hip", "p2p.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "pgemm.h", "gemm_s3.h", "tail.h", os.path.join("..", "..", "include", "vsn.h")]
 # md.hip holds every kernel whose per-atom arithmetic is shared between two launches (the step ends stand-alone and
 # fused with the integrator halves, csrc/tail.h): contraction is off for the whole file, so bit-identity between those

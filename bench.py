@@ -98,6 +98,13 @@ def parse_args(argv=None):
                          "device_strategy.py:84-127; default) or by edge count (measured: within 1 %% of each other, "
                          "DESIGN.md section 5 - the per-rank step is dominated by its size-independent part)")
     ap.add_argument("--chunk-edges", type=int, default=0, help="override vsn max_chunk_edges (workspace bound)")
+    ap.add_argument("--exchange", choices=("collective", "p2p"), default="collective",
+                    help="the exchange step of the sharded MD path: ONE all_gather_into_tensor per step (RCCL; default) "
+                         "or the tuned variant - every rank stores its slot straight into its peers' gather buffers "
+                         "(hipIpc-mapped, one HIP launch per step: csrc/p2p.hip)")
+    ap.add_argument("--dump-state", action="store_true",
+                    help="MD workloads: put float64 checksums of the final positions / velocities / forces into "
+                         "config.state_checksum (tests compare runs that must agree to the last bit)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="VALIDATION aid, not a measurement: N ranks on ONE GPU (device = LOCAL_RANK %% device count) "
                          "over gloo with device tensors - the real sharded product path (one HIP engine per rank, fused "
@@ -443,7 +450,8 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
         ff.emulate = True
     else:
         ff = ShardedFragmentForces.for_engine(eng, plan, rank=ctx.rank, world=ctx.world, group=ctx.group,
-                                              hydrogen=hplan, balance=args.balance)
+                                              hydrogen=hplan, balance=args.balance,
+                                              exchange=getattr(args, "exchange", "collective"))
     # ---- parity guard 2: the device pipeline (gather + cap-H + ViSNet shard + all-gather + combine) at step 0 ----
     if not args.emulate_shard:
         x0 = torch.as_tensor(prot.positions, dtype=torch.float32, device=dev)
@@ -496,6 +504,13 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
     chk = float(md.x.double().sum().item()) + float(md.v.double().sum().item()) if hasattr(md, "v") else float(md.x.double().sum().item())
     spread = ctx.max_over_ranks(chk) + ctx.max_over_ranks(-chk)  # max - min over the ranks
     assert spread == 0.0, f"ranks have diverged: checksum spread {spread!r} after {k} steps"
+    if ff.p2p is not None:
+        ff.p2p.check()  # every wait of the direct-write exchange completed (none gave up on a peer)
+    state_checksum = None
+    if getattr(args, "dump_state", False):
+        # (hex strings: the compact line rounds floats to 6 digits, these must survive to the last bit)
+        state_checksum = [float(t.double().sum().item()).hex() for t in (md.x, md.v, md.F)] + [
+            float(t.double().abs().sum().item()).hex() for t in (md.x, md.v, md.F)]
     ms = 1e3 * el / k
     n_loc = ff.local_rows
     # ---- instrumented pass: HIP events around every GEMM launch (same stream) ----
@@ -517,10 +532,15 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
                 f"friction 0.001/fs, harmonic tether {tether_k:g} eV/A^2 (random weights), "
                 f"ViSNet H={H} L={L} rbf={R} lmax=2 heads=8 cutoff=5")
     res = dict(metric=f"MD steps/sec on {PRETTY[pname]}", value=k / el, unit="steps/s", steps=k, ms_per_step=ms,
-               scaling="strong", config=dict(workload=workload, edges_local=edges_after,
+               scaling="strong", config=dict(workload=workload, exchange=("p2p direct peer writes (csrc/p2p.hip)"
+                                                                          if ff.p2p is not None else
+                                                                          "all_gather_into_tensor") if ctx.world > 1 or
+                                             ff.p2p is not None else "none (single rank)", edges_local=edges_after,
                                              edges_at_start_of_timed_region=edges_before, frag_atoms_local=n_loc,
                                              algorithmic_gflop_per_step_local=flops_step / 1e9),
                parity=par, roofline=roof)
+    if state_checksum is not None:
+        res["config"]["state_checksum"] = state_checksum
     if requested_run:
         # the driver's contract: "time EXACTLY K steps" - `value` / `steps` / `ms_per_step` are the K it asked for; the
         # 1000-step loop BASELINE configs[1] is defined on is measured right behind it, same state, and rides in config
@@ -535,6 +555,62 @@ def run_md(ctx, eng, hp, pname, args, steps, warmup, gold_suffix="", mm=None, te
         res["roofline"]["hbm"] = roof_hbm
     res["roofline"]["step_bound"] = bound
     return res, (plan, prot, md)
+
+
+def collective_delta(ctx, eng, hp, pname, args, steps=300, rounds=3):
+    """What ONE `all_gather_into_tensor` per MD step costs on this software stack, MEASURED: the same sharded step with
+    `force_collective=True` (a world-1 RCCL process group: ProcessGroupNCCL host enqueue, the event hand-off between
+    the compute stream and RCCL's stream, RCCL's own launch) against the collective-free loop, same protein, same
+    state, `rounds` alternating blocks of `steps` steps, median of the per-block differences.  A single rank moves no
+    bytes over xGMI: this is the software floor of the exchange step every rank of an N-rank job pays, not the wire.
+    Only where no process group exists yet (N = 1) and a GPU is present; never part of `value`."""
+    import torch.distributed as dist
+
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+    from ai2bmd_amd.fragmentation import build_plan
+    from ai2bmd_amd.md import LangevinHIP
+
+    if ctx.world != 1 or dist.is_initialized():
+        return None
+    prot = load_protein(pname)
+    plan = build_plan(prot)
+    hplan = None
+    if not args.no_relax_caps:
+        from ai2bmd_amd.amber import load_tables
+        from ai2bmd_amd.hydrogen import build_hydrogen_plan
+
+        hplan = build_hydrogen_plan(prot, plan, load_tables(os.path.join(GOLD, "amber_tables.npz")))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(ctx.dev))
+    try:
+        mds = {}
+        for coll in (False, True):
+            ff = ShardedFragmentForces.for_engine(eng, plan, hydrogen=hplan, force_collective=coll)
+            mds[coll] = LangevinHIP(prot.numbers, prot.positions, ff.step, ctx.dev, seed=0, tether_k=5.0)
+            for _ in range(10):
+                mds[coll].step()
+        torch.cuda.synchronize()
+        per = {False: [], True: []}
+        for _ in range(rounds):
+            for coll in (False, True):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    mds[coll].step()
+                torch.cuda.synchronize()
+                per[coll].append(1e3 * (time.perf_counter() - t0) / steps)
+        # same draws, same arithmetic: the all-gather of one rank is a copy of its own slot
+        same = bool(torch.equal(mds[False].x, mds[True].x))
+        d = sorted(a - b for a, b in zip(per[True], per[False]))
+        return dict(workload=f"{pname}_md", steps_per_block=steps, blocks=rounds,
+                    ms_per_step_without=float(np.median(per[False])), ms_per_step_with=float(np.median(per[True])),
+                    delta_us=1e3 * d[len(d) // 2], delta_us_min=1e3 * d[0], delta_us_max=1e3 * d[-1],
+                    trajectories_bit_identical=same, slot_bytes=int(ff.slot * 4),
+                    what="world-1 RCCL all_gather_into_tensor every step (torch.distributed ProcessGroupNCCL) minus the "
+                         "collective-free loop: the software cost of the exchange step, no xGMI traffic")
+    finally:
+        dist.destroy_process_group()
 
 
 def run_frag_batch(ctx, eng, hp, args, steps, warmup):
@@ -719,8 +795,9 @@ def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16, kee
     t0 = time.perf_counter()
     for _ in range(nbatch):
         step()
-    consume(0)
-    consume(1)
+    # the two batches still in flight, in BATCH order (the float64 checksums are sums in the order 0, 1, 2, ...)
+    for b in sorted((0, 1), key=lambda b_: -1 if state["held"][b_] is None else state["held"][b_]):
+        consume(b)
     copy.synchronize()
     ctx.barrier()
     el = ctx.max_over_ranks(time.perf_counter() - t0)
@@ -887,10 +964,32 @@ def run_stub(ctx, args):
 
 
 # ------------------------------------------------------------------------------------------------------------
+class StdoutGuard:
+    """Only the result line reaches the real stdout.  RCCL prints a version banner through C stdio when a communicator is
+    created; with stdout a pipe that text sits in a libc buffer until the process exits - AFTER the JSON line, which
+    then is no longer the last line the driver reads (seen on the first run that created a communicator).  From the
+    first line of main() file descriptor 1 is stderr for every library and every rank; `result_line` writes to the
+    saved descriptor."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.real = os.dup(1)
+        os.dup2(2, 1)
+
+    def result_line(self, line: str):
+        sys.stdout.flush()
+        os.write(self.real, (line + "\n").encode())
+
+
+_GUARD = None
+
+
 def main():
+    global _GUARD
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+    _GUARD = StdoutGuard()
     ctx = Ctx(args)
     if ctx.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
@@ -958,6 +1057,9 @@ def main():
             if ctx.rank == 0 and ctx.world == 1 and not args.no_cpu_baseline:
                 cpu = cpu_baseline_md(plan, prot, hp, sd)
             del md
+            if ctx.world == 1 and not args.emulate_shard and not args.no_secondary:
+                # the all-gather of the sharded path, measured instead of assumed
+                res["config"]["rccl1_allgather"] = {p_: collective_delta(ctx, eng, hp, p_, args) for p_ in ("chig", "ww")}
         elif args.workload == "frag_stream":
             res = run_frag_stream(ctx, eng, hp, args)
         else:
@@ -1085,11 +1187,14 @@ def compact_line(full: dict, detail_path: str | None = None, limit: int = LINE_L
     c = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "steps_requested", "warmup", "ms_per_step",
                      "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "rccl_ranks", "backend"))
     cfg = full.get("config", {})
-    cc = _pick(cfg, ("workload", "edges_local", "frag_atoms_local", "algorithmic_gflop_per_step_local",
+    cc = _pick(cfg, ("workload", "exchange", "state_checksum", "edges_local", "frag_atoms_local",
+                     "algorithmic_gflop_per_step_local",
                      "host_seam_evals_per_s_pcie_inclusive", "reference_shaped_step_calls_per_s",
                      "reference_caller_on_hip_seam_calls_per_s", "step_bound_ms"))
     if "c2_loop" in cfg:
         cc["c2_loop"] = _pick(cfg["c2_loop"], ("steps", "ms_per_step", "value", "unit"))
+    if isinstance(cfg.get("rccl1_allgather"), dict):  # the measured software cost of the one collective per step
+        cc["rccl1_allgather_delta_us"] = {k: (v or {}).get("delta_us") for k, v in cfg["rccl1_allgather"].items()}
     if "requested_run" in cfg:  # (records of rounds <= 5a: value on the 1000-step loop, the requested K beside it)
         cc["requested_run"] = _pick(cfg["requested_run"], ("steps", "ms_per_step", "value", "unit"))
     summ = {}
@@ -1162,7 +1267,10 @@ def emit(full: dict, args) -> None:
     print("BENCH_FULL_DETAIL (not the result line) " + json.dumps(full), file=sys.stderr, flush=True)
     line = json.dumps(compact_line(full, path), separators=(",", ":"))
     assert len(line) <= LINE_LIMIT and "\n" not in line, len(line)
-    print(line, flush=True)
+    if _GUARD is not None:
+        _GUARD.result_line(line)
+    else:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

@@ -147,6 +147,30 @@ int64_t vsn_debug_read(vsn_handle h, const char* name, int layer, void* host_out
 int vsn_gemm(vsn_handle h, const float* dev_A, int lda, const float* dev_Bt, int ldb, float* dev_C, int ldc,
              const float* dev_bias, int M, int Nc, int K, int flags, void* stream);
 
+/* ---- the exchange step of the sharded path as direct peer writes (SURVEY.md 8e "tuned variant") ----
+ * Replaces, for one process per GPU, what the reference does with worker processes and a host concatenate
+ * (Calculators/bonded.py:65-89, visnet_calculator.py:78-118): every rank's slot (forces of its fragment rows + energies
+ * of its fragments, `slot_floats` floats) is gathered on every rank.  One kernel per step STORES the rank's slot into
+ * each peer's gather buffer (buffers mapped with hipIpcGetMemHandle / hipIpcOpenMemHandle, xGMI point-to-point), raises
+ * a per-peer flag and waits for the peers' flags; double-buffered by step parity (csrc/p2p.hip).  Bitwise the buffer
+ * `torch.distributed.all_gather_into_tensor` produces; that call stays the default exchange.
+ *   create -> export (VSN_P2P_HANDLE_BYTES per rank) -> [the host all-gathers the handle records once, any transport]
+ *   -> connect -> per step: the rank's kernels write vsn_p2p_send_buffer(), then vsn_p2p_allgather(stream, &buf): `buf`
+ *   (device, [world][slot_floats]) is complete when the launch retires on `stream`.  All ranks must make the same
+ *   sequence of vsn_p2p_allgather calls; destroy only after every rank has finished its last one (host barrier).
+ * vsn_p2p_status synchronises `stream` and returns 0, or the step whose wait gave up after the timeout (a peer died). */
+typedef struct vsn_p2p* vsn_p2p_handle;
+#define VSN_P2P_HANDLE_BYTES 128
+int vsn_p2p_create(vsn_p2p_handle* out, int device_id, int rank, int world, int64_t slot_floats);
+int vsn_p2p_export(vsn_p2p_handle p, void* handle_bytes /* [VSN_P2P_HANDLE_BYTES] */);
+int vsn_p2p_connect(vsn_p2p_handle p, const void* all_handles /* [world][VSN_P2P_HANDLE_BYTES], rank order */);
+float* vsn_p2p_send_buffer(vsn_p2p_handle p);                 /* device f32 [slot_floats] */
+float* vsn_p2p_gather_buffer(vsn_p2p_handle p, int parity);   /* device f32 [world][slot_floats], parity 0 | 1 */
+int vsn_p2p_set_timeout(vsn_p2p_handle p, double seconds);    /* default 5 s */
+int vsn_p2p_allgather(vsn_p2p_handle p, void* stream, float** dev_gathered_out);
+int vsn_p2p_status(vsn_p2p_handle p, void* stream);
+void vsn_p2p_destroy(vsn_p2p_handle p);
+
 /* ---- overlap-force recombination (Calculators/combiner.py:24-41) ---- */
 typedef struct vsn_combine_plan* vsn_combine_handle;
 /* select/origin as in forces_combine; `n_dip_rows` = rows of the dipeptide

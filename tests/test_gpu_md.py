@@ -242,11 +242,13 @@ def test_injected_draws_hip_integrator_follows_the_torch_restatement_step_for_st
     cons = [Hookean(0, 5, 3.0, rt=1.0)]
     a.set_constraints(cons)
     b.set_constraints(cons)
+    # harmonic well: round-off only; the network's forces amplify the integrators' last-bit differences a little
+    tol = 1e-4 if fused else 2e-5
     for k in range(40):
         a.step()
         b.step()
-        np.testing.assert_allclose(b.x.cpu().numpy(), a.x.cpu().numpy(), rtol=0, atol=2e-5, err_msg=f"x, step {k}")
-        np.testing.assert_allclose(b.v.cpu().numpy(), a.v.cpu().numpy(), rtol=0, atol=2e-5, err_msg=f"v, step {k}")
+        np.testing.assert_allclose(b.x.cpu().numpy(), a.x.cpu().numpy(), rtol=0, atol=tol, err_msg=f"x, step {k}")
+        np.testing.assert_allclose(b.v.cpu().numpy(), a.v.cpu().numpy(), rtol=0, atol=tol, err_msg=f"v, step {k}")
     # the draws really entered: the same run on the built-in generator differs
     c = LangevinHIP(numbers, pos, fb, "cuda:0", seed=1, tether_k=0.7, velocities=v0, inplace_forces=fused)
     c.set_constraints(cons)

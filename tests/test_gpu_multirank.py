@@ -20,16 +20,21 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,workload,steps", [(2, "chig_md", 40), (8, "chig_md", 25), (4, "ww_md", 20)])
-def test_sharded_md_with_real_ranks_on_one_gpu(lib_built, world, workload, steps):
+def _run_shared(world, workload, steps, exchange):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "2"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu", "--workload",
-                        workload, "--steps", str(steps), "--warmup", "3", "--no-secondary", "--no-cpu-baseline"],
+                        workload, "--steps", str(steps), "--warmup", "3", "--no-secondary", "--no-cpu-baseline",
+                        "--exchange", exchange, "--dump-state"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    line = r.stdout.strip().splitlines()[-1]
-    out = json.loads(line)
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("world,workload,steps", [(2, "chig_md", 40), (8, "chig_md", 25), (4, "ww_md", 20)])
+def test_sharded_md_with_real_ranks_on_one_gpu(lib_built, world, workload, steps):
+    out = _run_shared(world, workload, steps, "collective")
     assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["backend"] == "gloo"
     assert out["data"].startswith("SHARED-GPU VALIDATION RUN") and out["steps"] == steps and out["scaling"] == "strong"
     p = out["parity"]
@@ -38,6 +43,24 @@ def test_sharded_md_with_real_ranks_on_one_gpu(lib_built, world, workload, steps
     # this rank's shard really is a shard
     full = dict(chig_md=391, ww_md=1387)[workload]
     assert 0 < out["config"]["frag_atoms_local"] < full
+
+
+@pytest.mark.parametrize("world,workload,steps", [(2, "chig_md", 40), (8, "chig_md", 25), (4, "ww_md", 20)])
+def test_p2p_exchange_is_the_collective_bit_for_bit(lib_built, world, workload, steps):
+    """The tuned exchange step (csrc/p2p.hip): every rank stores its slot straight into its peers' gather
+    buffers (hipIpcGetMemHandle / hipIpcOpenMemHandle mappings between the rank processes - here all on one device),
+    flags + waits in the same launch, double-buffered by step parity.  Same sharded MD run as above with
+    `--exchange p2p`: golden parity on every rank at step 0, all ranks bit-identical after the loop (bench.py asserts
+    both, and that no wait gave up), AND the final state equals the gloo-collective run's to the last bit - a copy is a
+    copy, whichever transport carried it."""
+    a = _run_shared(world, workload, steps, "collective")
+    b = _run_shared(world, workload, steps, "p2p")
+    assert b["config"]["exchange"].startswith("p2p") and a["config"]["exchange"] == "all_gather_into_tensor"
+    assert b["n_gpus"] == world and b["steps"] == steps
+    p = b["parity"]
+    assert p["pipeline_max_dF"] <= 1e-4 * max(1.0, p["max_abs_F"])
+    assert a["config"]["state_checksum"] == b["config"]["state_checksum"], (a["config"]["state_checksum"],
+                                                                             b["config"]["state_checksum"])
 
 
 WORKER_EMPTY = r'''

@@ -262,3 +262,39 @@ def test_profile_mode_times_every_node_walk_with_its_byte_model(lib_built):
     # k_bwd_hf1: L - 2 launches with the edge update, one (the last layer) without
     full = 4.0 * alg_floats("k_bwd_hf1", n, E)
     assert (L - 2) * full < w["k_bwd_hf1"]["bytes"] < (L - 1) * full
+
+
+def test_p2p_exchange_with_one_rank_is_the_collective_free_step(setup):
+    """`exchange="p2p"` at world == 1 (the rank stores its slot into its OWN gather buffer; csrc/p2p.hip): the same
+    forces and energy as the collective-free step, bit for bit, over several steps (both halves of the double buffer),
+    through the fused integrator ends too; no wait gives up."""
+    from ai2bmd_amd.bonded import ShardedFragmentForces
+    from ai2bmd_amd.md import LangevinHIP
+
+    hp, sd, prot, plan, model = setup
+    x = torch.as_tensor(prot.positions, dtype=torch.float32, device="cuda:0")
+    ref = ShardedFragmentForces.for_engine(model.engine, plan)
+    p2p = ShardedFragmentForces.for_engine(model.engine, plan, exchange="p2p")
+    assert p2p.p2p is not None and ref.p2p is None
+    for k in range(5):
+        xk = x + 0.01 * k
+        E0, F0 = ref.step(xk)
+        E0, F0 = float(E0), F0.clone()
+        E1, F1 = p2p.step(xk)
+        torch.cuda.synchronize()
+        assert E0 == float(E1) and torch.equal(F0, F1), k
+    p2p.p2p.check()
+    out = {}
+    for ex in ("collective", "p2p"):
+        ff = ShardedFragmentForces.for_engine(model.engine, plan, exchange=ex)
+        md = LangevinHIP(prot.numbers, prot.positions, ff.step, "cuda:0", seed=11, tether_k=2.0)
+        assert md._ff is not None
+        for _ in range(9):
+            md.step()
+        torch.cuda.synchronize()
+        out[ex] = (md.x.cpu().numpy().copy(), md.v.cpu().numpy().copy(), md.F.cpu().numpy().copy())
+        if ff.p2p is not None:
+            ff.p2p.check()
+            ff.p2p.close()
+    for a, b in zip(out["collective"], out["p2p"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)
