@@ -421,12 +421,14 @@ class ShardedFragmentForces:
         self.direct = True
         F_prot = torch.empty(plan.n_prot, 3, dtype=torch.float32, device=dev)
 
-        def local_fn(prot_pos, prebuilt=False):
+        def local_fn(prot_pos, prebuilt=0):
+            # prebuilt: 1 = the fragment geometry is already in pos_geo, 2 = and its cap hydrogens are relaxed (the
+            # integrator's fused first half did both: vsn_md_half1_build[_relax])
             st = tail.stream()
             if nloc:
                 if not prebuilt:
                     tail.build(self._fp, prot_pos, pos_geo, st)
-                if self.relaxer is not None:
+                if self.relaxer is not None and prebuilt != 2:
                     self.relaxer.run(pos_geo, st)
                 engine.forces_device(z_loc[:nloc], pos_loc[:nloc], self.local_start, self.local_end, e_loc[:bloc],
                                      f_loc[:nloc], stream=st)

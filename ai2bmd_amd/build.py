@@ -18,11 +18,15 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libvsn_hip.so")
 SOURCES = ["gemm.hip", "graph.hip", "layer_fwd.hip", "layer_bwd.hip", "fused.hip", "vecnorm.hip", "head.hip", "head_fused.hip", "md.hip", "mm.hip", "hydrogen.hip", "p2p.hip", "engine.hip"]
-HEADERS = ["common.h", "kernels.h", "pgemm.h", "gemm_s3.h", "tail.h", os.path.join("..", "..", "include", "vsn.h")]
+HEADERS = ["common.h", "kernels.h", "pgemm.h", "gemm_s3.h", "tail.h", "md_body.h", os.path.join("..", "..", "include", "vsn.h")]
 # md.hip holds every kernel whose per-atom arithmetic is shared between two launches (the step ends stand-alone and
 # fused with the integrator halves, csrc/tail.h): contraction is off for the whole file, so bit-identity between those
 # launches does not hang on per-function pragmas
-PER_FILE_FLAGS = {"md.hip": ["-ffp-contract=off"]}
+# hydrogen.hip launches the first Langevin half + fragment gather in front of its own optimiser (md_body.h, tail.h): the
+# same flag as md.hip, so the shared bodies compile to the same arithmetic in both files (measured: with contraction on
+# in this file - plain `fast` disregards the pragmas, `fast-honor-pragmas` still left 14 velocities one ulp off - the
+# fused start of a step was not bitwise the two launches it replaces)
+PER_FILE_FLAGS = {"md.hip": ["-ffp-contract=off"], "hydrogen.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 

@@ -148,6 +148,8 @@ def lib() -> C.CDLL:
     L.vsn_p2p_status.restype = C.c_int
     L.vsn_p2p_destroy.argtypes = [vp]
     L.vsn_p2p_destroy.restype = None
+    L.vsn_md_half1_build_relax.argtypes = [vp, f32p, f32p, f32p, vp, f32p, vp, vp]
+    L.vsn_md_half1_build_relax.restype = C.c_int
     L.vsn_md_set_noise.argtypes = [vp, vp, vp]
     L.vsn_md_set_noise.restype = C.c_int
     L.vsn_md_half1_build.argtypes = [vp, f32p, f32p, f32p, vp, f32p, vp]
@@ -192,6 +194,6 @@ EXPORTS = [
     "vsn_forces", "vsn_profile_read", "vsn_profile_read_scatter", "vsn_profile_read_walks", "vsn_walk_alg_bytes", "vsn_profile_bracket_ms", "vsn_last_num_edges", "vsn_last_status", "vsn_debug_read", "vsn_gemm", "vsn_combine_plan_create",
     "vsn_combine_plan_destroy", "vsn_combine", "vsn_combine_plan_set_energy", "vsn_combine_with_energy", "vsn_partition", "vsn_fragplan_create", "vsn_fragplan_destroy",
     "vsn_p2p_create", "vsn_p2p_export", "vsn_p2p_connect", "vsn_p2p_send_buffer", "vsn_p2p_gather_buffer", "vsn_p2p_set_timeout", "vsn_p2p_allgather", "vsn_p2p_status", "vsn_p2p_destroy",
-    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_set_noise", "vsn_md_half1_build", "vsn_md_combine_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
+    "vsn_build_fragments", "vsn_md_create", "vsn_md_destroy", "vsn_md_half1", "vsn_md_half2", "vsn_md_set_noise", "vsn_md_half1_build", "vsn_md_half1_build_relax", "vsn_md_combine_half2", "vsn_md_set_restraints", "vsn_md_restrain", "vsn_md_observe", "vsn_mm_create", "vsn_mm_destroy", "vsn_mm_forces",
     "vsn_hopt_create", "vsn_hopt_destroy", "vsn_hopt_run", "vsn_hopt_stats",
 ]

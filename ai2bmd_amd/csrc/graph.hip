@@ -12,6 +12,7 @@
 // Fragments of AI2BMD are tiny (<= 44 atoms): one workgroup per fragment, everything in LDS.  Batches holding a
 // larger fragment (whole-molecule mode, B = 1, up to VSN_MAX_FRAG_ATOMS) take the node-parallel passes below.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 #include "kernels.h"
@@ -248,6 +249,213 @@ __global__ void k_graph_bysrc_big(const float* __restrict__ pos, const int* __re
   if (!FILL) outdeg[j] = cnt;
 }
 
+// ---- single-protein sizes: the WHOLE graph + geometry in one launch (round 6) -----------------------------------------
+// An MD step of one protein is a chain of dependent launches, each with a ~5 us life of its own; degree count, CSR fill
+// and per-edge geometry were three of them (5.7 + 10.5 + 5.8 us on Chignolin) for a few microseconds of work.  What
+// forced the kernel boundaries was ONE number per fragment: the edge count of all earlier fragments (the base of its CSR
+// rows).  Here every workgroup derives it itself - the truncated in-degrees of the atoms in front of its fragment, a few
+// thousand distance tests spread over 256 threads (the same `<` on the same fp32 expression, so the same counts) - and
+// then builds rows, by-source view and geometry of its own edges with everything staged in LDS.
+// Same edges in the same order as the passes above (CSR by target, sources ascending, lowest-index max_nb kept).
+// Geometry: r, C, dC, exp(-alpha r) once per edge (k_edge_geom recomputes them for each of the Rp basis functions).
+#define VSN_GRAPH_MAXE (64 * 32)  // edges of one fragment: <= 64 targets x <= max_nb (<= 32 on this path) sources
+#define VSN_GRAPH_WAVES 16
+// Every neighbour test is ONE wave-wide comparison: lane j tests candidate j of the fragment, the ballot is the row of
+// the adjacency matrix, its population count the degree, the count of set bits below a lane the position of that source
+// in the (ascending) row - no serial scan over candidates anywhere.
+template <int DUMMY>
+__global__ __launch_bounds__(64 * VSN_GRAPH_WAVES) void k_graph_small_all(GraphArgs a) {
+  constexpr int NW = VSN_GRAPH_WAVES, NT = 64 * NW;
+  __shared__ float ps[64 * 3];
+  __shared__ int eid[64 * 65];  // eid[i*65 + j] = edge (j -> i) or -1 ; padded against bank conflicts
+  __shared__ unsigned short epair[VSN_GRAPH_MAXE];  // local edge -> (target << 8) | source
+  __shared__ float eC[VSN_GRAPH_MAXE], edC[VSN_GRAPH_MAXE], et[VSN_GRAPH_MAXE];  // C, dC, exp(-alpha r) (gauss: r)
+  __shared__ int red[NW];
+  __shared__ int sdeg[64], srow[64], sout[64], scol[64];
+  __shared__ int s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s = a.fstart[b], n = a.fend[b] - s;
+  // ---- base = sum of the truncated in-degrees of all atoms in front of this fragment (a wave per atom)
+  int part = 0;
+  for (int fb = 0; fb < b; ++fb) {
+    const int fs = a.fstart[fb], fn = a.fend[fb] - fs;
+    float xj = 0.f, yj = 0.f, zj = 0.f;
+    if (lane < fn) {
+      xj = a.pos[3 * (size_t)(fs + lane)];
+      yj = a.pos[3 * (size_t)(fs + lane) + 1];
+      zj = a.pos[3 * (size_t)(fs + lane) + 2];
+    }
+    for (int i = wave; i < fn; i += NW) {
+      // (candidate - target, like dist2(pos, j, i): the squares do not see the sign)
+      const float dx = xj - __shfl(xj, i, 64), dy = yj - __shfl(yj, i, 64), dz = zj - __shfl(zj, i, 64);
+      const bool in = lane < fn && __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)) < a.rc2;
+      const int cnt = __popcll(__ballot(in));
+      part += cnt < a.max_nb ? cnt : a.max_nb;  // (wave-uniform)
+    }
+  }
+  if (lane == 0) red[wave] = part;
+  for (int k = tid; k < 3 * n; k += NT) ps[k] = a.pos[3 * (size_t)s + k];
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) base += red[w];
+  // ---- rows of this fragment: a wave per target, lane = candidate source
+  unsigned long long keepm[(64 + NW - 1) / NW];
+#pragma unroll
+  for (int q = 0; q < (64 + NW - 1) / NW; ++q) {
+    const int i = wave + q * NW;
+    keepm[q] = 0ull;
+    if (i < n) {  // (wave-uniform)
+      bool in = false;
+      if (lane < n) {
+        const float dx = ps[3 * lane] - ps[3 * i], dy = ps[3 * lane + 1] - ps[3 * i + 1], dz = ps[3 * lane + 2] - ps[3 * i + 2];
+        in = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)) < a.rc2;
+      }
+      const unsigned long long m = __ballot(in);
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      keepm[q] = __ballot(in && rank < a.max_nb);  // the lowest-index max_nb sources
+      if (lane == 0) {
+        const int c = __popcll(m);
+        sdeg[i] = c < a.max_nb ? c : a.max_nb;
+      }
+    }
+  }
+  if (tid < n) {
+    const long long zv = a.z64[s + tid];
+    const bool bad = zv < 0 || zv >= (long long)a.z_limit;
+    if (bad) atomicMax(a.status, a.epoch);
+    a.zi[s + tid] = bad ? 0 : (int)zv;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int dv = lane < n ? sdeg[lane] : 0;
+    int incl = dv;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    srow[lane] = base + incl - dv;
+    if (lane < n) a.rowptr[s + lane] = base + incl - dv;
+    if (lane == 63) {
+      s_cnt = incl;
+      if (b == a.B - 1) {  // the last fragment (possibly empty) closes the arrays
+        a.rowptr[a.N] = base + incl;
+        a.colptr[a.N] = base + incl;
+        *a.ecount = base + incl;
+      }
+    }
+  }
+  __syncthreads();
+  if (n <= 0) return;  // (uniform per workgroup)
+#pragma unroll
+  for (int q = 0; q < (64 + NW - 1) / NW; ++q) {
+    const int i = wave + q * NW;
+    if (i < n && lane < n) {
+      const unsigned long long m = keepm[q];
+      int id = -1;
+      if ((m >> lane) & 1ull) {
+        id = srow[i] + __popcll(m & ((1ull << lane) - 1ull));
+        a.src[id] = s + lane;
+        a.tgt[id] = s + i;
+        epair[id - base] = (unsigned short)((i << 8) | lane);
+      }
+      eid[i * 65 + lane] = id;
+    }
+  }
+  __syncthreads();
+  // ---- the same edges by source: a wave per source j, lane = target i (ascending)
+#pragma unroll
+  for (int q = 0; q < (64 + NW - 1) / NW; ++q) {
+    const int j = wave + q * NW;
+    keepm[q] = 0ull;
+    if (j < n) {
+      const bool has = lane < n && eid[lane * 65 + j] >= 0;
+      keepm[q] = __ballot(has);
+      if (lane == 0) sout[j] = __popcll(keepm[q]);
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int dv = lane < n ? sout[lane] : 0;
+    int incl = dv;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    scol[lane] = base + incl - dv;
+    if (lane < n) a.colptr[s + lane] = base + incl - dv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < (64 + NW - 1) / NW; ++q) {
+    const int j = wave + q * NW;
+    if (j < n && lane < n) {
+      const unsigned long long m = keepm[q];
+      if ((m >> lane) & 1ull) a.perm[scol[j] + __popcll(m & ((1ull << lane) - 1ull))] = eid[lane * 65 + j];
+    }
+  }
+  // ---- geometry of this fragment's edges
+  const int ne = s_cnt;
+  const float pi_rc = 3.14159265358979323846f / a.rc;
+  for (int le = tid; le < ne; le += NT) {
+    const int pr = epair[le], i = pr >> 8, j = pr & 255;
+    const size_t e = (size_t)base + le;
+    const float ex = ps[3 * j] - ps[3 * i], ey = ps[3 * j + 1] - ps[3 * i + 1], ez = ps[3 * j + 2] - ps[3 * i + 2];
+    const bool loop = (i == j);
+    const float r = loop ? 0.f : sqrtf(ex * ex + ey * ey + ez * ez);
+    const float rinv = loop ? 0.f : 1.0f / r;
+    const float inside = (r < a.rc) ? 1.f : 0.f;
+    const float C = 0.5f * (cosf(r * pi_rc) + 1.0f) * inside;
+    const float dC = -0.5f * pi_rc * sinf(r * pi_rc) * inside;
+    eC[le] = C;
+    edC[le] = dC;
+    et[le] = a.rbf_type == 1 ? r : expf(-a.alpha * r);
+    const float ux = ex * rinv, uy = ey * rinv, uz = ez * rinv;
+    float4* g = reinterpret_cast<float4*>(a.geo + e * 8);
+    g[0] = make_float4(r, C, dC, ux);
+    g[1] = make_float4(uy, uz, rinv, 0.f);
+    const float s3 = 1.7320508075688772f;
+    float4* dd = reinterpret_cast<float4*>(a.d + e * 8);
+    if (a.S == 8) {
+      dd[0] = make_float4(ux, uy, uz, s3 * ux * uz);
+      dd[1] = make_float4(s3 * ux * uy, uy * uy - 0.5f * (ux * ux + uz * uz), s3 * uy * uz, 0.5f * s3 * (uz * uz - ux * ux));
+    } else {
+      dd[0] = make_float4(ux, uy, uz, 0.f);
+      dd[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  // rbf / drbf rows (and the cleared g_geo row): a wave walks whole edges, lane = basis function (Rp = 32: two edges)
+  const int Rp = a.Rp, R = a.R;
+  const float coeff = a.rbf_type == 1 ? a.betas[0] : 0.f;
+  const int per = Rp <= 32 ? 2 : 1;              // edges per wave pass
+  const int k = Rp <= 32 ? (lane & 31) : lane;   // (Rp is 32 or 64 on this path: num_rbf <= 64)
+  const float mu = k < R ? a.means[k] : 0.f, be = (k < R && a.rbf_type != 1) ? a.betas[k] : 0.f;
+  for (int le = wave * per + (Rp <= 32 ? (lane >> 5) : 0); le < ne; le += NW * per) {
+    const size_t e = (size_t)base + le;
+    if (k < VSN_GEO_W && k < Rp) a.g_geo[e * VSN_GEO_W + k] = 0.f;  // the reverse pass accumulates dE/dd, dE/dC per edge here
+    float v = 0.f, dv = 0.f;
+    if (k < R) {
+      const float C = eC[le], dC = edC[le], t = et[le];
+      if (a.rbf_type == 1) {  // GaussianSmearing: exp(coeff (r - offset_k)^2), no cutoff factor
+        const float dr = t - mu;
+        const float ek = expf(coeff * dr * dr);
+        v = ek;
+        dv = 2.0f * coeff * dr * ek;
+      } else {
+        const float ek = expf(-be * (t - mu) * (t - mu));
+        const float dek = 2.0f * a.alpha * be * t * (t - mu) * ek;
+        v = C * ek;
+        dv = dC * ek + C * dek;
+      }
+    }
+    if (k < Rp) {
+      a.rbf[e * Rp + k] = v;
+      a.drbf[e * Rp + k] = dv;
+    }
+  }
+}
+
 // per-edge geometry: one thread per (edge, rbf index); Rp = padded rbf count (multiple of 32)
 __global__ void k_edge_geom(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ tgt,
                             const int* __restrict__ ecount, const float* __restrict__ means,
@@ -445,8 +653,18 @@ __global__ __launch_bounds__(256) void k_force_gather_geom(int N, const int* __r
   }
 }
 
+// env VSN_GRAPH_FUSED=0: the three separate launches at single-protein sizes too (A/B aid)
+static int g_graph_fused = [] {
+  const char* e = getenv("VSN_GRAPH_FUSED");
+  return e ? atoi(e) : 1;
+}();
+
 int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.B <= 0 || a.N <= 0) return 0;
+  if (g_graph_fused && a.max_frag <= 64 && a.N < 4096 && a.max_nb <= 32 && a.Rp <= 64 && VSN_GEO_W <= 32) {
+    hipLaunchKernelGGL(k_graph_small_all<0>, dim3(a.B), dim3(64 * VSN_GRAPH_WAVES), 0, st, a);
+    return 0;
+  }
   if (a.max_frag <= 64) {
     hipLaunchKernelGGL(k_graph_count, dim3(a.B), dim3(64), 0, st, a.pos, a.z64, a.fstart, a.fend, a.deg, a.zi, a.rc2,
                        a.max_nb, a.z_limit, a.status, a.epoch);

@@ -17,6 +17,7 @@
 
 #include "../../include/vsn.h"
 #include "common.h"
+#include "md_body.h"
 
 #define HOPT_THREADS 1024
 #define HOPT_WAVES (HOPT_THREADS / VSN_WAVE)
@@ -156,12 +157,11 @@ __device__ double evaluate(const HoptDev& a, const float* pos, float* g, double*
   return block_sum(e_acc, sh);  // its barriers also publish g
 }
 
-__global__ __launch_bounds__(HOPT_THREADS) void k_hopt(HoptDev a, float* pos) {
+__device__ __forceinline__ void hopt_body(const HoptDev& a, float* pos, float* lws) {
   __shared__ double sh[HOPT_WAVES];
   // the optimiser state (a few KB: 3 n_cap floats per vector, 3 + 2 max_iter vectors) lives in LDS: every phase of the
   // loop is a write - barrier - read of these vectors by other threads (Chignolin: 24.6 -> 23.5 us per step; what is
   // left are the two energy evaluations and ~20 fp64 workgroup reductions of a 16-wave workgroup)
-  extern __shared__ __attribute__((aligned(16))) float lws[];
   const int n = 3 * a.ncap, tid = threadIdx.x;
   float* g = a.ws_in_lds ? lws : a.ws;
   float* gp = g + n;
@@ -269,6 +269,30 @@ __global__ __launch_bounds__(HOPT_THREADS) void k_hopt(HoptDev a, float* pos) {
     a.estats[0] = loss0;
     a.estats[1] = loss;
   }
+}
+
+__global__ __launch_bounds__(HOPT_THREADS) void k_hopt(HoptDev a, float* pos) {
+  extern __shared__ __attribute__((aligned(16))) float lws[];
+  hopt_body(a, pos, lws);
+}
+
+// The START of an MD step in one launch (round 6): first Langevin half + fragment-geometry gather of the new positions
+// (= k_md_half1_build, md.hip) + the cap-hydrogen relaxation of those fragments (= k_hopt).  All three are single
+// 1024-thread workgroups and strictly serial, so as two launches the step began with 9 + 24 us of which ~6 us were a
+// second launch's life.  Same device functions, contraction fixed per function body: the same bits as the two
+// launches (tests/test_gpu_pipeline.py::test_fused_integrator_ends_...).
+__global__ __launch_bounds__(HOPT_THREADS) void k_md_half1_build_hopt(
+    int n, const float* __restrict__ mass, const float* __restrict__ c3, const float* __restrict__ c4,
+    const float* __restrict__ c5, float c1, float c2, float dt, unsigned long long seed, unsigned step, float* x,
+    float* __restrict__ v, const float* __restrict__ F, float* __restrict__ rnd_vel, const float* __restrict__ ext_xi,
+    const float* __restrict__ ext_eta, vsn::FragView fp, float* frag_pos, HoptDev a) {
+  extern __shared__ __attribute__((aligned(16))) float lws[];
+  vsn::md_half1_body(n, mass, c3, c4, c5, c1, c2, dt, seed, step, x, v, F, rnd_vel, ext_xi, ext_eta);
+  __syncthreads();
+  const float* xn = x;
+  for (int k = threadIdx.x; k < fp.n; k += blockDim.x) vsn::build_row(k, fp.src, fp.acc, fp.tow, fp.len, xn, frag_pos);
+  __syncthreads();
+  hopt_body(a, frag_pos, lws);
 }
 
 // ---- C ABI ------------------------------------------------------------------------------------------------------
@@ -396,6 +420,20 @@ extern "C" void vsn_hopt_destroy(vsn_hopt_handle p) {
 extern "C" int vsn_hopt_run(vsn_hopt_handle p, float* dev_frag_pos, void* stream) {
   if (!p || !dev_frag_pos) return -22;
   hipLaunchKernelGGL(k_hopt, dim3(1), dim3(HOPT_THREADS), p->lds_bytes, (hipStream_t)stream, p->dev, dev_frag_pos);
+  return hipGetLastError() == hipSuccess ? 0 : -5;
+}
+
+extern "C" int vsn_md_half1_build_relax(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F,
+                                         vsn_fragplan_handle plan, float* dev_frag_pos, vsn_hopt_handle hopt,
+                                         void* stream) {
+  if (!p || !plan || !dev_frag_pos || !hopt) return -22;
+  vsn::FragView fv;
+  if (vsn_fragplan_view(plan, &fv) || fv.device != p->device || hopt->device != p->device) return -22;
+  if (hipSetDevice(p->device) != hipSuccess) return -19;
+  hipLaunchKernelGGL(k_md_half1_build_hopt, dim3(1), dim3(HOPT_THREADS), hopt->lds_bytes, (hipStream_t)stream, p->n,
+                     p->mass, p->c3, p->c4, p->c5, p->c1, p->c2, p->dt, p->seed, p->step, dev_x, dev_v, dev_F,
+                     p->rnd_vel, p->ext_xi, p->ext_eta, fv, dev_frag_pos, hopt->dev);
+  p->step++;
   return hipGetLastError() == hipSuccess ? 0 : -5;
 }
 

@@ -239,6 +239,7 @@ class LangevinHIP(_MDBase):
         self.force_fn = force_fn
         self.inplace_forces = bool(inplace_forces)
         self._ff = self._fusable_evaluator(force_fn, device) if (fuse_tail and inplace_forces) else None
+        self._fuse_relax = os.environ.get("VSN_MD_FUSE_RELAX", "1") != "0"  # A/B switch
         self.tether_k = float(tether_k)
         self._x0 = x0.astype(np.float64)
         self.constraints = []
@@ -339,11 +340,20 @@ class LangevinHIP(_MDBase):
         if self.rng is not None:
             self._upload_noise()
         fp, cp, frag_pos, F_prot, E_tot = self._ff.fused_tail
-        rc = self._L.vsn_md_half1_build(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
-                                        C.c_void_p(self.F.data_ptr()), fp, C.c_void_p(frag_pos.data_ptr()), st)
+        relaxer = getattr(self._ff, "relaxer", None)
+        if relaxer is not None and self._fuse_relax:
+            # + the cap-hydrogen relaxation of the gathered fragments: the whole start of the step in one launch
+            rc = self._L.vsn_md_half1_build_relax(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                                  C.c_void_p(self.F.data_ptr()), fp, C.c_void_p(frag_pos.data_ptr()),
+                                                  relaxer._h, st)
+            built = 2
+        else:
+            rc = self._L.vsn_md_half1_build(self._h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                                            C.c_void_p(self.F.data_ptr()), fp, C.c_void_p(frag_pos.data_ptr()), st)
+            built = 1
         if rc:
-            raise RuntimeError(f"vsn_md_half1_build failed ({rc})")
-        buf = self._ff.exchange(self.x, prebuilt=True)
+            raise RuntimeError(f"vsn_md_half1_build[_relax] failed ({rc})")
+        buf = self._ff.exchange(self.x, prebuilt=built)
         rc = self._L.vsn_md_combine_half2(self._h, cp, C.c_void_p(buf.data_ptr()), C.c_void_p(F_prot.data_ptr()),
                                           C.c_void_p(E_tot.data_ptr()), C.c_void_p(self.x.data_ptr()),
                                           C.c_void_p(self.v.data_ptr()), st)

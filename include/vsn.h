@@ -230,6 +230,12 @@ int vsn_md_half1_build(vsn_md_handle p, float* dev_x, float* dev_v, const float*
                        float* dev_frag_pos, void* stream);
 int vsn_md_combine_half2(vsn_md_handle p, vsn_combine_handle plan, const float* dev_buf, float* dev_F,
                          float* dev_e_out, const float* dev_x, float* dev_v, void* stream);
+/*   vsn_md_half1_build_relax = vsn_md_half1_build, then vsn_hopt_run(hopt) on dev_frag_pos - the whole start of a step
+ *                           (Langevin half, DistanceFragment.get_fragments: placement distancefrag.py:35-54 + L-BFGS
+ *                           relaxation hydrogen/energies.py:211-242) in ONE launch; bitwise the two calls. */
+struct vsn_hopt;
+int vsn_md_half1_build_relax(vsn_md_handle p, float* dev_x, float* dev_v, const float* dev_F, vsn_fragplan_handle plan,
+                             float* dev_frag_pos, struct vsn_hopt* hopt, void* stream);
 /* Replaces the restraint set (synchronises the device).  Point springs: atom[t] towards origin3[3t..], force
  * k (r - rt) along the line when r > rt, energy k (r - rt)^2 / 2 - `Hookean(a1=idx, a2=pos, k, rt)`, the
  * pre-equilibration stages (simulator.py:139-166).  Pair springs between atoms a1[t], a2[t] - `Hookean(a1, a2, k, rt)`,
