@@ -263,27 +263,40 @@ __global__ void k_graph_bysrc_big(const float* __restrict__ pos, const int* __re
 // Every neighbour test is ONE wave-wide comparison: lane j tests candidate j of the fragment, the ballot is the row of
 // the adjacency matrix, its population count the degree, the count of set bits below a lane the position of that source
 // in the (ascending) row - no serial scan over candidates anywhere.
+#define VSN_GRAPH_POOL (64 * 65 + 3 * VSN_GRAPH_MAXE)  // floats: eid + eC + edC + et ... or the staged positions
+#define VSN_GRAPH_MAXB 1024                            // fragment offsets staged in LDS
 template <int DUMMY>
 __global__ __launch_bounds__(64 * VSN_GRAPH_WAVES) void k_graph_small_all(GraphArgs a) {
   constexpr int NW = VSN_GRAPH_WAVES, NT = 64 * NW;
   __shared__ float ps[64 * 3];
-  __shared__ int eid[64 * 65];  // eid[i*65 + j] = edge (j -> i) or -1 ; padded against bank conflicts
+  // one pool, two lives: first the positions of every atom in FRONT of this fragment (the base count below walks
+  // earlier fragments one after the other: from global memory that was one dependent ~1 us round trip per fragment,
+  // 20 us for the last fragment of Chignolin), then the edge-id matrix and the per-edge geometry terms
+  __shared__ __attribute__((aligned(16))) float pool[VSN_GRAPH_POOL];
+  __shared__ int sfs[VSN_GRAPH_MAXB + 1];
+  int* eid = reinterpret_cast<int*>(pool);  // eid[i*65 + j] = edge (j -> i) or -1 ; padded against bank conflicts
+  float* eC = pool + 64 * 65;               // C, dC, exp(-alpha r) (gauss: r) per local edge
+  float* edC = eC + VSN_GRAPH_MAXE;
+  float* et = edC + VSN_GRAPH_MAXE;
   __shared__ unsigned short epair[VSN_GRAPH_MAXE];  // local edge -> (target << 8) | source
-  __shared__ float eC[VSN_GRAPH_MAXE], edC[VSN_GRAPH_MAXE], et[VSN_GRAPH_MAXE];  // C, dC, exp(-alpha r) (gauss: r)
   __shared__ int red[NW];
   __shared__ int sdeg[64], srow[64], sout[64], scol[64];
   __shared__ int s_cnt;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = a.fstart[b], n = a.fend[b] - s;
+  for (int k = tid; k < 3 * s; k += NT) pool[k] = a.pos[k];
+  for (int k = tid; k < b; k += NT) sfs[k] = a.fstart[k];
+  if (tid == 0) sfs[b] = s;  // (fragments are contiguous: end of fb = start of fb + 1)
+  __syncthreads();
   // ---- base = sum of the truncated in-degrees of all atoms in front of this fragment (a wave per atom)
   int part = 0;
   for (int fb = 0; fb < b; ++fb) {
-    const int fs = a.fstart[fb], fn = a.fend[fb] - fs;
+    const int fs = sfs[fb], fn = sfs[fb + 1] - fs;
     float xj = 0.f, yj = 0.f, zj = 0.f;
     if (lane < fn) {
-      xj = a.pos[3 * (size_t)(fs + lane)];
-      yj = a.pos[3 * (size_t)(fs + lane) + 1];
-      zj = a.pos[3 * (size_t)(fs + lane) + 2];
+      xj = pool[3 * (fs + lane)];
+      yj = pool[3 * (fs + lane) + 1];
+      zj = pool[3 * (fs + lane) + 2];
     }
     for (int i = wave; i < fn; i += NW) {
       // (candidate - target, like dist2(pos, j, i): the squares do not see the sign)
@@ -293,6 +306,7 @@ __global__ __launch_bounds__(64 * VSN_GRAPH_WAVES) void k_graph_small_all(GraphA
       part += cnt < a.max_nb ? cnt : a.max_nb;  // (wave-uniform)
     }
   }
+  __syncthreads();  // (the pool is about to change hands)
   if (lane == 0) red[wave] = part;
   for (int k = tid; k < 3 * n; k += NT) ps[k] = a.pos[3 * (size_t)s + k];
   __syncthreads();
@@ -661,7 +675,8 @@ static int g_graph_fused = [] {
 
 int launch_graph(hipStream_t st, const GraphArgs& a) {
   if (a.B <= 0 || a.N <= 0) return 0;
-  if (g_graph_fused && a.max_frag <= 64 && a.N < 4096 && a.max_nb <= 32 && a.Rp <= 64 && VSN_GEO_W <= 32) {
+  if (g_graph_fused && a.max_frag <= 64 && 3 * a.N <= VSN_GRAPH_POOL && a.B <= VSN_GRAPH_MAXB && a.max_nb <= 32 &&
+      a.Rp <= 64 && VSN_GEO_W <= 32) {
     hipLaunchKernelGGL(k_graph_small_all<0>, dim3(a.B), dim3(64 * VSN_GRAPH_WAVES), 0, st, a);
     return 0;
   }

@@ -19,7 +19,9 @@
 #include "common.h"
 #include "md_body.h"
 
-#define HOPT_THREADS 1024
+#ifndef HOPT_THREADS
+#define HOPT_THREADS 1024  // (A/B builds: -DHOPT_THREADS=512)
+#endif
 #define HOPT_WAVES (HOPT_THREADS / VSN_WAVE)
 #define HOPT_MAX_ITER 16
 

@@ -111,7 +111,13 @@ static inline int node_block(int wpn) { return wpn == 1 ? 256 : 64 * wpn; }
 static inline size_t node_lds(int wpn, int K, int V) {
   const int rmax = (32 / V) < 8 ? (32 / V) : 8;  // node_reduce: RMAX rows per pass
   const int kc = K < rmax ? K : rmax;
-  return wpn == 1 ? 0 : (size_t)(wpn - 1) * kc * V * 64 * 4;
+  // (env VSN_BATCH_LDS_PAD: lab knob - unused dynamic LDS on the one-wave-per-node launches caps the workgroups a CU
+  //  holds, i.e. the nodes in flight per XCD whose gathered rows compete for its 4 MB of L2)
+  static const size_t pad = [] {
+    const char* e = getenv("VSN_BATCH_LDS_PAD");
+    return e ? (size_t)atol(e) : (size_t)0;
+  }();
+  return wpn == 1 ? pad : (size_t)(wpn - 1) * kc * V * 64 * 4;
 }
 
 // ---- adjoint of the node update (visnet_block.py:271-274) ------------------------

@@ -584,16 +584,18 @@ def collective_delta(ctx, eng, hp, pname, args, steps=300, rounds=3):
     os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(ctx.dev))
     try:
-        mds = {}
-        for coll in (False, True):
-            ff = ShardedFragmentForces.for_engine(eng, plan, hydrogen=hplan, force_collective=coll)
+        mds, ffs = {}, {}
+        for coll in (False, True, "p2p"):
+            ff = ShardedFragmentForces.for_engine(eng, plan, hydrogen=hplan, force_collective=(coll is True),
+                                                  exchange="p2p" if coll == "p2p" else "collective")
+            ffs[coll] = ff
             mds[coll] = LangevinHIP(prot.numbers, prot.positions, ff.step, ctx.dev, seed=0, tether_k=5.0)
             for _ in range(10):
                 mds[coll].step()
         torch.cuda.synchronize()
-        per = {False: [], True: []}
+        per = {False: [], True: [], "p2p": []}
         for _ in range(rounds):
-            for coll in (False, True):
+            for coll in (False, True, "p2p"):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(steps):
@@ -601,11 +603,17 @@ def collective_delta(ctx, eng, hp, pname, args, steps=300, rounds=3):
                 torch.cuda.synchronize()
                 per[coll].append(1e3 * (time.perf_counter() - t0) / steps)
         # same draws, same arithmetic: the all-gather of one rank is a copy of its own slot
-        same = bool(torch.equal(mds[False].x, mds[True].x))
+        same = bool(torch.equal(mds[False].x, mds[True].x)) and bool(torch.equal(mds[False].x, mds["p2p"].x))
+        ffs["p2p"].p2p.check()
         d = sorted(a - b for a, b in zip(per[True], per[False]))
+        dp = sorted(a - b for a, b in zip(per["p2p"], per[False]))
         return dict(workload=f"{pname}_md", steps_per_block=steps, blocks=rounds,
                     ms_per_step_without=float(np.median(per[False])), ms_per_step_with=float(np.median(per[True])),
                     delta_us=1e3 * d[len(d) // 2], delta_us_min=1e3 * d[0], delta_us_max=1e3 * d[-1],
+                    # the tuned exchange (csrc/p2p.hip: one launch that stores the slot, raises and awaits the flags),
+                    # same protocol: a single rank stores into its own buffer - the launch and its flag round trip
+                    p2p_ms_per_step=float(np.median(per["p2p"])), p2p_delta_us=1e3 * dp[len(dp) // 2],
+                    p2p_delta_us_min=1e3 * dp[0], p2p_delta_us_max=1e3 * dp[-1],
                     trajectories_bit_identical=same, slot_bytes=int(ff.slot * 4),
                     what="world-1 RCCL all_gather_into_tensor every step (torch.distributed ProcessGroupNCCL) minus the "
                          "collective-free loop: the software cost of the exchange step, no xGMI traffic")
@@ -1195,6 +1203,7 @@ def compact_line(full: dict, detail_path: str | None = None, limit: int = LINE_L
         cc["c2_loop"] = _pick(cfg["c2_loop"], ("steps", "ms_per_step", "value", "unit"))
     if isinstance(cfg.get("rccl1_allgather"), dict):  # the measured software cost of the one collective per step
         cc["rccl1_allgather_delta_us"] = {k: (v or {}).get("delta_us") for k, v in cfg["rccl1_allgather"].items()}
+        cc["p2p1_exchange_delta_us"] = {k: (v or {}).get("p2p_delta_us") for k, v in cfg["rccl1_allgather"].items()}
     if "requested_run" in cfg:  # (records of rounds <= 5a: value on the 1000-step loop, the requested K beside it)
         cc["requested_run"] = _pick(cfg["requested_run"], ("steps", "ms_per_step", "value", "unit"))
     summ = {}

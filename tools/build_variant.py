@@ -21,7 +21,7 @@ def main():
 
     def cc(src):
         obj = os.path.join(out, f"{tag}_{src.replace('.hip', '.o')}")
-        subprocess.run([B._hipcc(), *B.FLAGS, *defs, "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
+        subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), *defs, "-c", os.path.join(B.CSRC, src), "-o", obj], check=True)
         return obj
 
     with ThreadPoolExecutor(4) as ex:
