@@ -15,9 +15,9 @@
 //
 // so when the kernel retires every slot of this step has landed in THIS rank's buffer and the combine that follows on
 // the same stream reads it after a kernel boundary.  Buffers are mapped into the peers with hipIpcGetMemHandle /
-// hipIpcOpenMemHandle (one process per GPU); the flags live in fine-grained (uncached) memory so that a running
-// kernel sees remote stores.  `par` = step & 1: a peer that runs ahead writes step s + 1 into the OTHER half; it can
-// only reach step s + 2 after this rank's flag for s + 1, which this rank stores after its combine of step s (stream
+// hipIpcOpenMemHandle (one process per GPU); gather buffer and flags live in fine-grained memory so that a running
+// kernel sees the peers' flag stores and the combine never reads a stale cached line of a slot a peer has rewritten.
+// `par` = step & 1: a peer that runs ahead writes step s + 1 into the OTHER half; it can only reach step s + 2 after this rank's flag for s + 1, which this rank stores after its combine of step s (stream
 // order) - no slot is overwritten while it may still be read.  The step counter is monotonic, so a flag never has to
 // be reset.  A wait that lasts longer than `timeout` (default 5 s: a peer died) gives up and raises the handle's
 // status instead of hanging the GPU.
@@ -89,7 +89,9 @@ extern "C" int vsn_p2p_create(vsn_p2p_handle* out, int device_id, int rank, int 
   p->world = world;
   p->slot = (int)slot_floats;
   const size_t nd = (size_t)2 * world * slot_floats * sizeof(float);
-  bool ok = hipMalloc((void**)&p->data, nd) == hipSuccess &&
+  // gather buffer AND flags in fine-grained device memory: a peer's stores arrive over the fabric, not through this
+  // GPU's L2s - fine-grained lines are never served stale from them (a few KB per step: no cost worth measuring)
+  bool ok = hipExtMallocWithFlags((void**)&p->data, nd, hipDeviceMallocFinegrained) == hipSuccess &&
             hipExtMallocWithFlags((void**)&p->flags, (size_t)world * sizeof(unsigned), hipDeviceMallocFinegrained) ==
                 hipSuccess &&
             hipMalloc((void**)&p->send, (size_t)slot_floats * sizeof(float)) == hipSuccess &&

@@ -40,6 +40,35 @@ def _world_sizes():
     return out
 
 
+def _run_ranks(world, workload, exchange):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "2"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", workload,
+                        "--steps", "50", "--warmup", "5", "--no-secondary", "--no-cpu-baseline", "--exchange", exchange,
+                        "--dump-state"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines  # the result line ALONE on stdout (RCCL's banner goes to stderr: bench.StdoutGuard)
+    return json.loads(lines[-1])
+
+
+@need2
+@pytest.mark.parametrize("workload", ["ww_md", "chig_md"])
+@pytest.mark.parametrize("world", _world_sizes())
+def test_p2p_exchange_over_xgmi_is_the_rccl_collective_bit_for_bit(lib_built, world, workload):
+    """the tuned exchange step across REAL devices: every rank stores its slot into its peers' IPC-mapped buffers over
+    xGMI (csrc/p2p.hip) - same final state as the RCCL all-gather run, to the last bit"""
+    if world > NDEV:
+        pytest.skip(f"{world} ranks need {world} GPUs")
+    a = _run_ranks(world, workload, "collective")
+    b = _run_ranks(world, workload, "p2p")
+    assert b["config"]["exchange"].startswith("p2p") and b["backend"] == "nccl"
+    assert a["config"]["state_checksum"] == b["config"]["state_checksum"]
+    p = b["parity"]
+    assert p["pipeline_max_dF"] <= 1e-4 * max(1.0, p["max_abs_F"])
+
+
 @need2
 @pytest.mark.parametrize("workload", ["ww_md", "chig_md"])
 @pytest.mark.parametrize("world", _world_sizes())
@@ -47,14 +76,7 @@ def test_sharded_md_over_rccl(lib_built, world, workload):
     """bench.py launches its own ranks (torch.distributed.run, 127.0.0.1) when started without RANK in the environment"""
     if world > NDEV:
         pytest.skip(f"{world} ranks need {world} GPUs")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    env["OMP_NUM_THREADS"] = "2"
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", workload,
-                        "--steps", "50", "--warmup", "5", "--no-secondary", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out = _run_ranks(world, workload, "collective")
     assert out["n_gpus"] == world and out["rccl_ranks"] == world and out["backend"] == "nccl"
     assert out["steps"] == 50 and out["scaling"] == "strong" and out["value"] > 0
     p = out["parity"]

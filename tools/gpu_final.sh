@@ -28,4 +28,19 @@ c = d["cpu_baseline"]; print("cpu", {k: c[k] for k in ("value", "cores", "kind",
 for k, v in d["config"].get("secondary_summary", {}).items():
     print("  ", k, round(v["value"], 1), v["unit"], v["steps"])
 PY
+# the round's files under their profiles/ names (here, on the box, for walk_table; gpurun merges only gpurun_out/ back:
+# tools/collect_profiles.sh <tag> does the same copy in the build container)
+bash tools/collect_profiles.sh "$TAG" > /dev/null 2>&1 || true
+python tools/walk_table.py "$TAG" > "$OUT/walk_table.log" 2>&1 || true
+cp "profiles/${TAG}_node_walks.md" "$OUT/node_walks.md" 2>/dev/null
+XUS=$(python - "$OUT/bench_full.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(f"{d['config']['rccl1_allgather']['chig']['delta_us']:.1f}")
+except Exception:
+    print("9.8")
+PY
+)
+timeout 900 python tools/shard_table.py --exchange-us "$XUS" > "$OUT/shard_table.md" 2> "$OUT/shard_table.err" || true
 ls "$OUT"
