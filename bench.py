@@ -237,8 +237,25 @@ def count_edges(pos, start, end, cutoff, max_nb):
     return tot
 
 
-def parity_check(what, E, F, E64, F64, tol_f=1e-4, tol_e=1e-5):
-    """SURVEY.md 8c tolerance (fp32 contract vs the reference's fp64 result); aborts the run on mismatch."""
+class ParityFailure(SystemExit):
+    """a workload failed its parity guard.  Raised on EVERY rank at the same point (the verdict is agreed over the ranks
+    before anybody raises), so a secondary can be dropped by all ranks together; fatal for the primary workload."""
+
+
+_CTX = None  # the run's Ctx (set by main): parity verdicts are agreed over its ranks
+
+
+def _agreed(ok: bool) -> bool:
+    """True only if `ok` on every rank (one all-reduce where a process group exists; outside every timed region)"""
+    if _CTX is None or _CTX.world == 1:
+        return bool(ok)
+    return _CTX.max_over_ranks(0.0 if ok else 1.0) == 0.0
+
+
+def parity_check(what, E, F, E64, F64, tol_f=1e-4, tol_e=1e-5, collective=True):
+    """SURVEY.md 8c tolerance (fp32 contract vs the reference's fp64 result); raises ParityFailure on mismatch - on all
+    ranks when any rank mismatches (`collective`; the in-stream check of run_frag_stream passes False and settles its
+    verdict after the loop)."""
     E, F = np.asarray(E, np.float64).reshape(-1), np.asarray(F, np.float64)
     E64, F64 = np.asarray(E64, np.float64).reshape(-1), np.asarray(F64, np.float64)
     ok = E.shape == E64.shape and F.shape == F64.shape and np.isfinite(E).all() and np.isfinite(F).all()
@@ -250,9 +267,11 @@ def parity_check(what, E, F, E64, F64, tol_f=1e-4, tol_e=1e-5):
     if not ok and os.environ.get("VSN_LAB_NO_PARITY"):  # lab ablations compute wrong numbers on purpose (tools/lab)
         print(f"LAB RUN, NOT A MEASUREMENT: parity check skipped ({what})", file=sys.stderr)
         return dict(max_dE=de, max_dF=df, force_mae=mae, max_abs_F=float("nan"), LAB_NO_PARITY=True)
-    if not ok:
-        raise SystemExit(f"PARITY FAILURE before the timed region ({what}): max|dE|={de:.3e} max|dF|={df:.3e} "
-                         f"MAE={mae:.3e} against the reference-source golden - refusing to print a bench line")
+    ok_all = _agreed(ok) if collective else ok
+    if not ok_all:
+        where = "" if not ok else " (this rank passed; another rank did not)"
+        raise ParityFailure(f"PARITY FAILURE before the timed region ({what}): max|dE|={de:.3e} max|dF|={df:.3e} "
+                            f"MAE={mae:.3e} against the reference-source golden{where}")
     return dict(max_dE=de, max_dF=df, force_mae=mae, max_abs_F=float(np.abs(F64).max()))
 
 
@@ -765,10 +784,14 @@ def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16, kee
         state["sumF2"] += float(np.square(f_, dtype=np.float64).sum())
         state["consumed"] += 1
         if bi % golden_every == 0 and bi < nbatch:
-            pr = parity_check(f"streamed batch {bi}, golden block", e_[:ng], f_[:ngat], E_gold, F_gold)
+            try:
+                pr = parity_check(f"streamed batch {bi}, golden block", e_[:ng], f_[:ngat], E_gold, F_gold,
+                                  collective=False)
+                state["gold_dF"] = max(state["gold_dF"], pr["max_dF"])
+                state["gold_dE"] = max(state["gold_dE"], pr["max_dE"])
+            except ParityFailure as exc:  # settled over the ranks after the loop (no collective inside the clock)
+                state["gold_fail"] = state.get("gold_fail") or str(exc)
             state["gold"] += 1
-            state["gold_dF"] = max(state["gold_dF"], pr["max_dF"])
-            state["gold_dE"] = max(state["gold_dE"], pr["max_dE"])
         state["held"][b] = None
 
     for b in range(2):
@@ -810,6 +833,8 @@ def run_frag_stream(ctx, eng, hp, args, conformations=None, golden_every=16, kee
     ctx.barrier()
     el = ctx.max_over_ranks(time.perf_counter() - t0)
     k = nbatch
+    if not _agreed(not state.get("gold_fail")):
+        raise ParityFailure(state.get("gold_fail") or "PARITY FAILURE in the streamed golden blocks of another rank")
     assert state["consumed"] == nbatch and math.isfinite(state["sumE"]) and math.isfinite(state["sumF"])
     if keep is not None:  # tests: the inputs of every batch, to re-evaluate them one by one outside the pipe
         keep.update(z=z_all, pos=pn, start=start, end=end)
@@ -999,10 +1024,27 @@ def main():
         sys.exit(self_launch(args))
     _GUARD = StdoutGuard()
     ctx = Ctx(args)
+    global _CTX
+    _CTX = ctx
     if ctx.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
     secondary = []
+    dropped = []
     cpu = None
+
+    def guarded(label, fn):
+        """A SECONDARY that fails its parity guard must not take the headline with it (seen once: the opt-in split-3
+        batch on rank 1 of a two-rank shared-GPU run).  ParityFailure is raised on all ranks at the same point, so all
+        ranks drop the secondary together; it is named, with the reason, in config.secondary_dropped."""
+        try:
+            return fn()
+        except ParityFailure as exc:
+            dropped.append(dict(secondary=label, reason=str(exc)[:300]))
+            print(f"SECONDARY DROPPED ({label}): {exc}", file=sys.stderr, flush=True)
+            if not ctx.stub:
+                torch.cuda.synchronize()
+            return None
+
     if args.stub:
         res = run_stub(ctx, args)
         data = "STUB"
@@ -1077,56 +1119,71 @@ def main():
             # collective), Trp-cage (configs[2]) and, sharded over N > 1 GPUs, the WW domain (configs[3])
             extra_md = ["trpcage", "ww"]  # (WW at N = 1 as well: the 1-GPU anchor of the sharded curve)
             for pname in extra_md:
-                r2, keep = run_md(ctx, eng, hp, pname, args, 400 if pname == "trpcage" else 300, 10)
-                del keep
-                secondary.append(r2)
-            secondary.append(run_frag_batch(ctx, eng, hp, args, 6, 1))
+                got = guarded(f"{pname}_md", lambda: run_md(ctx, eng, hp, pname, args, 400 if pname == "trpcage" else 300, 10))
+                if got is not None:
+                    secondary.append(got[0])
+                del got
+            r_fb = guarded("frag_batch", lambda: run_frag_batch(ctx, eng, hp, args, 6, 1))
+            if r_fb is not None:
+                secondary.append(r_fb)
             # configs[4] as stated: NEW conformations every step, H2D / D2H inside the timed region
-            secondary.append(run_frag_stream(ctx, eng, hp, args))
+            r_fs = guarded("frag_stream_pcie", lambda: run_frag_stream(ctx, eng, hp, args))
+            if r_fs is not None:
+                secondary.append(r_fs)
             # configs[1] (ii): + MM non-bonded.  Short, and on a 10x stiffer tether: with random ViSNet weights nothing
             # but the tether holds polar hydrogens against the Coulomb term (AMBER gives them no LJ core), and at
             # 5 eV/A^2 the structure loses 20 % of its edges within 300 steps - the edge-count assertion of run_md
             # refuses such a run
             a_mm = argparse.Namespace(**vars(args))
-            r_mm, keep = run_md(ctx, eng, hp, "chig", a_mm, 200, 10, mm=True, tether_k=50.0)
-            del keep
-            r_mm["metric"] += " + MM non-bonded"
-            secondary.append(r_mm)
+            got = guarded("chig_md_mm", lambda: run_md(ctx, eng, hp, "chig", a_mm, 200, 10, mm=True, tether_k=50.0))
+            if got is not None:
+                r_mm = got[0]
+                r_mm["metric"] += " + MM non-bonded"
+                secondary.append(r_mm)
+            del got
             # SURVEY 8(d) small variant (H = 128, L = 6), its own engine and its own reference-source golden
             hp_s = default_hparams(embedding_dimension=128, num_layers=6)
             eng_s = ViSNetEngine(hp_s, make_state_dict(hp_s, seed=2024), ctx.dev)
             a_s = argparse.Namespace(**vars(args))
-            r_s, keep = run_md(ctx, eng_s, hp_s, "chig", a_s, 600, 10, gold_suffix="_h128l6")
-            del keep, eng_s
-            r_s["metric"] += " (small variant H=128 L=6)"
-            secondary.append(r_s)
+            got = guarded("chig_md_h128l6", lambda: run_md(ctx, eng_s, hp_s, "chig", a_s, 600, 10, gold_suffix="_h128l6"))
+            if got is not None:
+                r_s = got[0]
+                r_s["metric"] += " (small variant H=128 L=6)"
+                secondary.append(r_s)
+            del got, eng_s
             # opt-in arithmetic mode, NEVER the headline: the grouped products as 3 x bf16 split MFMA products with fp32
             # accumulation (csrc/gemm_s3.h).  Same workload, same goldens, same tolerance; its own parity block.
+            split3_dtype = "f32 operands as 3 x bf16 split terms (six bf16 MFMA products per k-block), f32 accumulate"
+            split3_note = ("fp32-EQUIVALENT FLOP/s of the split products against the fp32 matrix peak (the bf16 pipe does "
+                           "6/16 of the fp32 form's matrix cycles): a mode label, not an fp32 MFMA utilisation")
             eng.set_option("gemm_split3", 1)
             try:
-                r_3, keep = run_md(ctx, eng, hp, "chig", args, C2_STEPS, 10)
+                got = guarded("chig_md_split3_optin", lambda: run_md(ctx, eng, hp, "chig", args, C2_STEPS, 10))
             finally:
                 eng.set_option("gemm_split3", 0)
-            del keep
-            r_3["metric"] += " (opt-in mode gemm_split3)"
-            r_3["dtype"] = "f32 operands as 3 x bf16 split terms (six bf16 MFMA products per k-block), f32 accumulate"
-            r_3["roofline"]["note"] = ("fp32-EQUIVALENT FLOP/s of the split products against the fp32 matrix peak (the "
-                                       "bf16 pipe does 6/16 of the fp32 form's matrix cycles): a mode label, not an "
-                                       "fp32 MFMA utilisation")
-            r_3["keep_parity"] = True
-            secondary.append(r_3)
+            if got is not None:
+                r_3 = got[0]
+                r_3["metric"] += " (opt-in mode gemm_split3)"
+                r_3["dtype"] = split3_dtype
+                r_3["roofline"]["note"] = split3_note
+                r_3["keep_parity"] = True
+                secondary.append(r_3)
+            del got
             # the same mode on the fragment batch (plain products on the 128 x 128 split tile; the fused panel
             # products keep their fp32 MFMA kernels)
             eng.set_option("gemm_split3", 1)
             try:
-                r_b3 = run_frag_batch(ctx, eng, hp, args, 6, 1)
+                r_b3 = guarded("frag_batch_split3_optin", lambda: run_frag_batch(ctx, eng, hp, args, 6, 1))
             finally:
                 eng.set_option("gemm_split3", 0)
-            r_b3["metric"] += " (opt-in mode gemm_split3)"
-            r_b3["dtype"] = r_3["dtype"]
-            r_b3["roofline"]["note"] = r_3["roofline"]["note"]
-            r_b3["keep_parity"] = True
-            secondary.append(r_b3)
+            if r_b3 is not None:
+                r_b3["metric"] += " (opt-in mode gemm_split3)"
+                r_b3["dtype"] = split3_dtype
+                r_b3["roofline"]["note"] = split3_note
+                r_b3["keep_parity"] = True
+                secondary.append(r_b3)
+    if dropped:
+        res["config"]["secondary_dropped"] = dropped
     out = dict(
         metric=res["metric"], value=res["value"], unit=res["unit"], n_gpus=ctx.world, steps=res["steps"],
         steps_requested=args.steps_requested, warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True,
@@ -1201,6 +1258,8 @@ def compact_line(full: dict, detail_path: str | None = None, limit: int = LINE_L
                      "reference_caller_on_hip_seam_calls_per_s", "step_bound_ms"))
     if "c2_loop" in cfg:
         cc["c2_loop"] = _pick(cfg["c2_loop"], ("steps", "ms_per_step", "value", "unit"))
+    if cfg.get("secondary_dropped"):
+        cc["secondary_dropped"] = cfg["secondary_dropped"]
     if isinstance(cfg.get("rccl1_allgather"), dict):  # the measured software cost of the one collective per step
         cc["rccl1_allgather_delta_us"] = {k: (v or {}).get("delta_us") for k, v in cfg["rccl1_allgather"].items()}
         cc["p2p1_exchange_delta_us"] = {k: (v or {}).get("p2p_delta_us") for k, v in cfg["rccl1_allgather"].items()}

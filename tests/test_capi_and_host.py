@@ -348,3 +348,33 @@ def test_committed_bench_line_keeps_the_contract():
     else:
         assert len(raw) <= bench.LINE_LIMIT
     _check_result_line(d)
+
+
+def test_parity_failure_is_agreed_over_the_ranks_before_anybody_raises(monkeypatch):
+    """bench.parity_check: a mismatch raises ParityFailure (a SystemExit: fatal for the primary workload, caught per
+    secondary in main()).  With a process group the verdict is all-reduced first, so every rank leaves the workload at the
+    same point - a rank that passed raises too when another one failed (a lone raise would leave the others waiting in
+    their next collective)."""
+    import numpy as np
+
+    import bench
+
+    E, F = np.ones(3), np.ones((5, 3))
+    ok = bench.parity_check("same", E, F, E, F)
+    assert ok["max_dF"] == 0.0
+    with pytest.raises(bench.ParityFailure) as ei:
+        bench.parity_check("off", E, F + 1e-2, E, F)
+    assert isinstance(ei.value, SystemExit) and "PARITY FAILURE" in str(ei.value)
+
+    class TwoRanks:  # the other rank failed: max over ranks of the failure flag is 1
+        world = 2
+
+        @staticmethod
+        def max_over_ranks(v):
+            return max(v, 1.0)
+
+    monkeypatch.setattr(bench, "_CTX", TwoRanks)
+    with pytest.raises(bench.ParityFailure, match="another rank"):
+        bench.parity_check("mine is fine", E, F, E, F)
+    # the in-stream check settles its verdict after the loop: no collective inside the clock
+    assert bench.parity_check("local", E, F, E, F, collective=False)["max_dE"] == 0.0
