@@ -1476,7 +1476,9 @@ extern "C" int vsn_gemm(vsn_handle c, const float* A, int lda, const float* Bt, 
     }
     if (scratch) set_gemm_splitk_workspace(scratch, scratch_elems);
   }
+  set_gemm_split3(c->gemm_split3 ? c->s3 : nullptr);  // (the tap follows the handle's arithmetic mode like vsn_forces)
   int rc = launch_gemm((hipStream_t)stream, A, lda, Bt, ldb, C, ldc, bias, M, nullptr, Nc, K, flags);
+  set_gemm_split3(nullptr);
   set_gemm_splitk_workspace(nullptr, 0);
   if (rc) return fail(c, rc, "gemm: unsupported shape (K, Nc multiples of 32; lda/ldb/ldc multiples of 4; A, Bt, C, bias 16-byte aligned)");
   hipError_t le = hipGetLastError();

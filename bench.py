@@ -1156,11 +1156,17 @@ def main():
             split3_dtype = "f32 operands as 3 x bf16 split terms (six bf16 MFMA products per k-block), f32 accumulate"
             split3_note = ("fp32-EQUIVALENT FLOP/s of the split products against the fp32 matrix peak (the bf16 pipe does "
                            "6/16 of the fp32 form's matrix cycles): a mode label, not an fp32 MFMA utilisation")
-            eng.set_option("gemm_split3", 1)
-            try:
-                got = guarded("chig_md_split3_optin", lambda: run_md(ctx, eng, hp, "chig", args, C2_STEPS, 10))
-            finally:
-                eng.set_option("gemm_split3", 0)
+            # (not while several ranks SHARE one GPU: a neighbour process that runs the split-3 GEMM perturbs the results of
+            #  the other process's kernels on that device - measured, LAB_NOTES section 15; one process per GPU, the
+            #  product configuration, never showed it)
+            run_split3 = not ctx.share_gpu
+            got = None
+            if run_split3:
+                eng.set_option("gemm_split3", 1)
+                try:
+                    got = guarded("chig_md_split3_optin", lambda: run_md(ctx, eng, hp, "chig", args, C2_STEPS, 10))
+                finally:
+                    eng.set_option("gemm_split3", 0)
             if got is not None:
                 r_3 = got[0]
                 r_3["metric"] += " (opt-in mode gemm_split3)"
@@ -1171,11 +1177,13 @@ def main():
             del got
             # the same mode on the fragment batch (plain products on the 128 x 128 split tile; the fused panel
             # products keep their fp32 MFMA kernels)
-            eng.set_option("gemm_split3", 1)
-            try:
-                r_b3 = guarded("frag_batch_split3_optin", lambda: run_frag_batch(ctx, eng, hp, args, 6, 1))
-            finally:
-                eng.set_option("gemm_split3", 0)
+            r_b3 = None
+            if run_split3:
+                eng.set_option("gemm_split3", 1)
+                try:
+                    r_b3 = guarded("frag_batch_split3_optin", lambda: run_frag_batch(ctx, eng, hp, args, 6, 1))
+                finally:
+                    eng.set_option("gemm_split3", 0)
             if r_b3 is not None:
                 r_b3["metric"] += " (opt-in mode gemm_split3)"
                 r_b3["dtype"] = split3_dtype
