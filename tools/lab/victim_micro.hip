@@ -39,11 +39,12 @@ __global__ void k_sload(const float* x, const float* table, float* y, int rows) 
   if (wave >= rows) return;
   const int w = __builtin_amdgcn_readfirstlane(wave);
   float acc = 0.f;
-  for (int k = 0; k < 16; ++k) {
+  const int iters = gridDim.y > 1 ? 4096 : 16;  // (grid.y == 2: the long form - milliseconds of scalar loads per launch)
+  for (int k = 0; k < iters; ++k) {
     const float c = table[(size_t)((w * 7 + k * 13) % rows) * 8 + 1];  // uniform address: a scalar load
     acc += x[(size_t)w * 64 + lane] * c;
   }
-  y[(size_t)w * 64 + lane] = acc;
+  if (blockIdx.y == 0) y[(size_t)w * 64 + lane] = acc;
 }
 __global__ void k_vload(const float* x, const float* table, float* y, int rows) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -70,12 +71,13 @@ int main(int argc, char** argv) {
   hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMalloc(&table, (size_t)rows * 8 * 4);
   hipMemcpy(x, h.data(), n * 4, hipMemcpyHostToDevice);
   std::vector<float> ref(n), cur(n);
-  const char* names[4] = {"trans", "shuffle", "sload", "vload"};
-  for (int mode = 0; mode < 4; ++mode) {
+  const char* names[5] = {"trans", "shuffle", "sload", "vload", "sload-long"};
+  for (int mode = 0; mode < 5; ++mode) {
     int bad = 0;
     for (int r = 0; r < R; ++r) {
       hipMemset(y, 0, n * 4);
       if (mode >= 2) hipLaunchKernelGGL(k_fill, dim3((rows * 8 + 255) / 256), dim3(256), 0, 0, table, rows, 0.5f);
+      if (mode == 4) hipLaunchKernelGGL(k_sload, dim3(n / 256, 2), dim3(256), 0, 0, x, table, y, rows);
       if (mode == 0) hipLaunchKernelGGL(k_trans, dim3(n / 256), dim3(256), 0, 0, x, y, n);
       if (mode == 1) hipLaunchKernelGGL(k_shuffle, dim3(n / 256), dim3(256), 0, 0, x, y, n);
       if (mode == 2) hipLaunchKernelGGL(k_sload, dim3(n / 256), dim3(256), 0, 0, x, table, y, rows);
