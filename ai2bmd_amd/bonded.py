@@ -243,18 +243,17 @@ class P2PExchange:
         if rc:
             raise RuntimeError(f"vsn_p2p_connect failed ({rc}): hipIpcOpenMemHandle refused a peer's buffer")
         self.send = torch.as_tensor(_DevView(self.L.vsn_p2p_send_buffer(self._h), self.slot), device=device)
-        self._bufs = [torch.as_tensor(_DevView(self.L.vsn_p2p_gather_buffer(self._h, k), world * self.slot), device=device)
-                      for k in (0, 1)]
-        self._step = 0
+        ptrs = [self.L.vsn_p2p_gather_buffer(self._h, k) for k in (0, 1)]
+        self._bufs = {int(ptr): torch.as_tensor(_DevView(ptr, world * self.slot), device=device) for ptr in ptrs}
         if world > 1:
             dist.barrier(group=group)  # every rank has mapped every buffer before the first store
 
     def gather(self, stream):
-        rc = self.L.vsn_p2p_allgather(self._h, C.c_void_p(stream.cuda_stream), None)
+        out = C.c_void_p()
+        rc = self.L.vsn_p2p_allgather(self._h, C.c_void_p(stream.cuda_stream), C.byref(out))
         if rc:
             raise RuntimeError(f"vsn_p2p_allgather failed ({rc})")
-        self._step += 1
-        return self._bufs[self._step & 1]
+        return self._bufs[int(out.value)]  # (the half of the double buffer the LIBRARY chose for this step)
 
     def check(self, stream=None):
         """synchronises; raises if a wait gave up (a peer never stored its slot)"""
