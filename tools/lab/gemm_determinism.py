@@ -19,6 +19,8 @@ if os.environ.get("GD_ONLY"):
 for (M, Nc, K) in shapes:
     A = torch.randn(M, K, device="cuda", generator=g)
     B = torch.randn(Nc, K, device="cuda", generator=g)
+    if os.environ.get("GD_ZERO"):  # (lab: an aggressor that moves nothing but zeros)
+        A.zero_(); B.zero_()
     for mode in ((1,) if os.environ.get("GD_ONLY") else (0, 1)):
         eng.set_option("gemm_split3", mode)
         outs = None
