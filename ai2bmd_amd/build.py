@@ -27,7 +27,15 @@ HEADERS = ["common.h", "kernels.h", "pgemm.h", "gemm_s3.h", "tail.h", "md_body.h
 # in this file - plain `fast` disregards the pragmas, `fast-honor-pragmas` still left 14 velocities one ulp off - the
 # fused start of a step was not bitwise the two launches it replaces)
 PER_FILE_FLAGS = {"md.hip": ["-ffp-contract=off"], "hydrogen.hip": ["-ffp-contract=off"]}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+# NO packed fp32 VALU instructions in the device code (target feature "packed-fp32-ops" off; the host pass prints an
+# "ignoring feature" note).  Measured on MI355X (tools/lab/pk_micro.hip, LAB_NOTES section 15): while a SECOND PROCESS
+# runs kernels on the same GPU, `v_pk_mul_f32 d, x, a op_sel:[0,1]` (both halves times a.hi - what the compiler emits
+# for "row times one factor") returns a wrong LOW half in lanes 48..63 about 3e-6 of the time - the attention walk's `m`
+# rows came out with 16 zeroed channels and a fragment batch differed by 1e-2 eV/A from call to call.  One process per GPU
+# never shows it; a library must not depend on that.  Scalar fp32 VALU is the same arithmetic (bit-identical results)
+# and costs nothing here: the walks wait for memory and the products run on MFMA (Chignolin 450.4 -> 454.9 steps/s).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", *NO_PACKED_FP32, "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
 
 def _hipcc() -> str:

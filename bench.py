@@ -1156,10 +1156,10 @@ def main():
             split3_dtype = "f32 operands as 3 x bf16 split terms (six bf16 MFMA products per k-block), f32 accumulate"
             split3_note = ("fp32-EQUIVALENT FLOP/s of the split products against the fp32 matrix peak (the bf16 pipe does "
                            "6/16 of the fp32 form's matrix cycles): a mode label, not an fp32 MFMA utilisation")
-            # (not while several ranks SHARE one GPU: a neighbour process that runs the split-3 GEMM perturbs the results of
-            #  the other process's kernels on that device - measured, LAB_NOTES section 15; one process per GPU, the
-            #  product configuration, never showed it)
-            run_split3 = not ctx.share_gpu
+            # (round 6 dropped these two from shared-GPU runs: a neighbour PROCESS on the device made packed fp32 VALU
+            #  instructions return wrong halves - LAB_NOTES section 15.  The library is built without those instructions
+            #  now, so the mode runs in every configuration again.)
+            run_split3 = True
             got = None
             if run_split3:
                 eng.set_option("gemm_split3", 1)

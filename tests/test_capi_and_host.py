@@ -22,6 +22,30 @@ def test_library_exports_every_declared_symbol(lib_built):
     assert sorted(capi.EXPORTS) == declared
 
 
+def test_shipped_code_objects_hold_no_packed_fp32_valu_instructions(lib_built, tmp_path):
+    """`v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32` must not appear in the gfx950 code of the library: on MI355X they
+    return wrong halves now and then while a second process uses the GPU (tools/lab/pk_micro.hip, LAB_NOTES section 15;
+    ai2bmd_amd/build.py NO_PACKED_FP32).  The GPU-side regression test is in tests/test_gpu_multirank.py; this one
+    catches a build whose flags lost the switch, without a GPU."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    lib = shutil.copy(lib_built if isinstance(lib_built, str) else os.path.join(ROOT, "ai2bmd_amd", "libvsn_hip.so"),
+                      tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert objs, os.listdir(tmp_path)
+    n_inst = 0
+    for f in objs:
+        dis = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        n_inst += dis.count("v_mul_f32") + dis.count("v_fma_f32") + dis.count("v_fmac_f32")
+        hits = re.findall(r"v_pk_(?:mul|fma|add)_f32|v_pk_mov_b32", dis)  # (the four instructions of the feature)
+        assert not hits, (f, sorted(set(hits)), len(hits))
+    assert n_inst > 1000  # (the disassembly really was device code)
+
+
 def test_create_fails_loudly_without_gpu_or_bad_hparams(lib_built):
     import torch
 

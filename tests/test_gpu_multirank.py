@@ -130,3 +130,62 @@ def test_ranks_that_own_nothing_with_real_engines(lib_built, tmp_path):
     for k in range(8):
         assert f"rank {k} ok" in r.stdout
     assert r.stdout.count("frags=0 fused=False") == 3 and r.stdout.count("fused=True") == 5
+
+
+WORKER_BATCH = r'''
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from ai2bmd_amd.synthetic import default_hparams, make_state_dict
+from ai2bmd_amd.visnet_calculator import ViSNetEngine
+G = os.path.join(sys.argv[1], "tests", "golden")
+pool = []
+for name in ("chig", "trpcage", "ww", "abd"):
+    g = np.load(os.path.join(G, f"visnet_prot_{name}.npz"))
+    for a, b in zip(g["start"], g["end"]):
+        pool.append((g["z"][a:b], g["pos_relaxed"][a:b]))
+rng = np.random.default_rng(7)
+zs, ps, sizes = [], [], []
+for i in range(2048):
+    z, p = pool[i % len(pool)]
+    zs.append(z); sizes.append(len(z)); ps.append(p if i < len(pool) else p + rng.normal(0, 0.05, size=p.shape))
+end = np.cumsum(sizes); start = end - np.asarray(sizes)
+z = torch.as_tensor(np.concatenate(zs), dtype=torch.int64).cuda()
+pos = torch.as_tensor(np.concatenate(ps).astype(np.float32)).cuda()
+hp = default_hparams()
+eng = ViSNetEngine(hp, make_state_dict(hp, seed=2024), "cuda:0")
+open(sys.argv[2] + ".ready", "w").close()          # both processes evaluate at the same time
+t0 = time.time()
+while not os.path.exists(sys.argv[3] + ".ready") and time.time() - t0 < 300:
+    time.sleep(0.05)
+outs = []
+for r in range(int(sys.argv[4])):
+    e = torch.empty(len(start), device="cuda:0"); f = torch.empty(len(z), 3, device="cuda:0")
+    eng.forces_device(z, pos, start, end, e, f)
+    torch.cuda.synchronize()
+    outs.append((e.cpu().numpy(), f.cpu().numpy()))
+bad = [r for r in range(1, len(outs)) if not (np.array_equal(outs[r][0], outs[0][0]) and np.array_equal(outs[r][1], outs[0][1]))]
+np.savez(sys.argv[2] + ".npz", e=outs[0][0], f=outs[0][1], bad=np.asarray(bad, dtype=np.int64))
+'''
+
+
+def test_batch_evaluation_is_bit_reproducible_next_to_a_second_process_on_the_gpu(lib_built, tmp_path):
+    """Two PROCESSES on one GPU, each evaluating the same 2048-fragment batch again and again while the other does the
+    same: every evaluation of both must be the same bits.  Found in round 6 (LAB_NOTES section 15,
+    tools/lab/pk_micro.hip): on this hardware `v_pk_mul_f32 ... op_sel:[0,1]` returns a wrong low half in lanes 48..63
+    now and then while ANOTHER process runs kernels on the device; a build with packed fp32 VALU instructions had 7 of 8
+    such evaluations differ (max |dF| 2e-2 eV/A, zeroed channels in the attention messages).  The library is compiled
+    without them (ai2bmd_amd/build.py NO_PACKED_FP32)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_BATCH)
+    tags = [str(tmp_path / "a"), str(tmp_path / "b")]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, tags[i], tags[1 - i], "8"], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i in range(2)]
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    import numpy as np
+    a, b = (np.load(t + ".npz") for t in tags)
+    assert a["bad"].size == 0 and b["bad"].size == 0, (a["bad"], b["bad"])
+    assert np.array_equal(a["e"], b["e"]) and np.array_equal(a["f"], b["f"])  # and the two processes agree

@@ -16,20 +16,24 @@
 # victims used in section 15:   'python tools/lab/determinism_probe.py 10 fp32'     whole evaluation, checksum per run
 #                               'python tools/lab/tap_probe.py 8 400'               first differing buffer
 #                               'python tools/lab/torch_victim.py 300'              library kernels
-#                               'tools/lab/victim_micro 400', 'tools/lab/stale_micro 3000 256'   micro-kernels
+#                               'python tools/lab/tap_pattern.py 5 400'             WHAT differs in that buffer
+#                               'tools/lab/pk_micro 300'                            packed-fp32 instructions alone
+#                               'tools/lab/victim_micro 400', 'tools/lab/stale_micro 3000 256'   other micro-kernels
 #   environment of a victim goes in its command: 'AMD_SERIALIZE_KERNEL=3 python tools/lab/determinism_probe.py 8 fp32',
 #   'VSN_OPTS=fuse_panel=0 python ...', 'HIP_FORCE_DEV_KERNARG=0 python ...', 'VSN_LIB=$PWD/ai2bmd_amd/_ab/x.so python ...'
 set -u
 agg=${1:?aggressor}; shift
 python -c "import torch; torch.zeros(1).cuda()"   # page the image in before anything is timed against a sleep
-filt() { grep -v amdgpu.ids | grep -E "pid|victim|burner|first|differ|stale|ok|FAIL" | cut -c1-220; }
+filt() { grep -v amdgpu.ids | cut -c1-${PROBE_COLS:-400}; }
+AGG_LOG=$(mktemp); AGG=
+agg_start() { env "$@" > "$AGG_LOG" 2>&1 & AGG=$!; }   # (the PID is `timeout`'s: a TERM to it ends the aggressor itself)
 case $agg in
   none|self)    ;;
-  gemm3)        (VSN_LIB=${AGGRESSOR_LIB:-} GD_ONLY=1 timeout 900 python tools/lab/gemm_determinism.py 90000 2>&1 | filt) & ;;
-  gemm3-zero)   (VSN_LIB=${AGGRESSOR_LIB:-} GD_ZERO=1 GD_ONLY=1 timeout 900 python tools/lab/gemm_determinism.py 90000 2>&1 | filt) & ;;
-  batch-split3) (timeout 900 python tools/lab/determinism_probe.py 1500 split3 2>&1 | filt) & ;;
-  batch-fp32)   (PROBE_SEED=99 timeout 900 python tools/lab/determinism_probe.py 1500 fp32 2>&1 | filt) & ;;
-  lib-bf16|lib-fp16|lib-fp32) (timeout 900 python tools/lab/burner_dtype.py 600 ${agg#lib-} 2>&1 | filt) & ;;
+  gemm3)        agg_start VSN_LIB=${AGGRESSOR_LIB:-} GD_ONLY=1 timeout 900 python tools/lab/gemm_determinism.py 90000 ;;
+  gemm3-zero)   agg_start VSN_LIB=${AGGRESSOR_LIB:-} GD_ZERO=1 GD_ONLY=1 timeout 900 python tools/lab/gemm_determinism.py 90000 ;;
+  batch-split3) agg_start timeout 900 python tools/lab/determinism_probe.py 1500 split3 ;;
+  batch-fp32)   agg_start PROBE_SEED=99 timeout 900 python tools/lab/determinism_probe.py 1500 fp32 ;;
+  lib-bf16|lib-fp16|lib-fp32) agg_start timeout 900 python tools/lab/burner_dtype.py 600 ${agg#lib-} ;;
   *) echo "unknown aggressor $agg" >&2; exit 2 ;;
 esac
 [ "$agg" = none ] || [ "$agg" = self ] || sleep 14
@@ -39,4 +43,5 @@ for v in "$@"; do
   timeout 500 bash -c "$v" 2>&1 | filt
   [ "$agg" = self ] && wait
 done
-[ "$agg" = none ] || [ "$agg" = self ] || { kill %1 2>/dev/null; wait 2>/dev/null; }
+if [ -n "$AGG" ]; then kill $AGG 2>/dev/null; wait $AGG 2>/dev/null; echo "--- aggressor:"; filt < "$AGG_LOG"; fi
+rm -f "$AGG_LOG"
