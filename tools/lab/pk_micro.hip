@@ -1,11 +1,10 @@
 // lab: do PACKED fp32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32) give wrong results while a second PROCESS uses the
 // same GPU?  (LAB_NOTES section 15: the attention walk's `m` rows came out with the LOW half of one packed product
 // zeroed in lanes 48..63, only next to a neighbour process, and not at all in a build without packed fp32 ops.)
-//   asm   : v_pk_mul_f32 d, x, a op_sel:[0,1]  (both halves times a.hi - the form the compiler emits for "row times one
-//           factor") in a long register-only loop, every result checked against two plain v_mul_f32; mismatches are
-//           counted per 16-lane quarter and half, and per wave whether its HW_ID / XCC_ID changed during the kernel
-//           (a wave that moved was context-saved and restored)
-//   plain : the same without op_sel (lo x lo, hi x hi)
+//   v_pk_*: seven forms of the packed instructions (mul / fma / add, with and without op_sel / op_sel_hi; see k_pk) in a
+//           long register-only loop, every result checked against two plain scalar-VALU instructions; mismatches are
+//           counted per 16-lane quarter and half, one wrong product is printed with its operands, and per wave whether
+//           its HW_ID / XCC_ID changed during the kernel (a wave that moved was context-saved and restored)
 //   walk  : compiler-generated code of the attention walk's shape (row loads, fast sigmoid, 8-lane head sums, row times
 //           head factor, row store), launched again and again on the same inputs and compared with its first output
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast tools/lab/pk_micro.hip -o tools/lab/pk_micro
@@ -22,6 +21,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 struct Stats {
   unsigned long long bad[4][2];   // [16-lane quarter][half]
   unsigned long long waves, moved, bad_in_moved, bad_in_unmoved;
+  unsigned sample_taken;
+  float sample[6];                // x.lo x.hi a.lo a.hi | packed low result | scalar low result   of one wrong product
 };
 
 template <int MODE>
@@ -35,14 +36,45 @@ __global__ __launch_bounds__(256) void k_pk(const float* __restrict__ xin, Stats
   for (int k = 0; k < iters; ++k) {
     v2f d;
     float lo, hi;
+    // MODE 0: mul op_sel:[0,1]     lo = x.lo a.hi   hi = x.hi a.hi      (the form found in the attention walk)
+    //      1: mul                  lo = x.lo a.lo   hi = x.hi a.hi
+    //      2: fma op_sel:[0,1,0]   lo = x.lo a.hi + x.lo, hi = x.hi a.hi + x.hi
+    //      3: mul op_sel:[1,0]     lo = x.hi a.lo   hi = x.hi a.hi
+    //      4: mul op_sel_hi:[1,0]  lo = x.lo a.lo   hi = x.hi a.lo
+    //      5: add op_sel:[0,1]     lo = x.lo + a.hi hi = x.hi + a.hi
+    //      6: mul op_sel:[1,1]     lo = x.hi a.hi   hi = x.hi a.hi
     if (MODE == 0) {
       asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
       asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.x), "v"(a.y));
-    } else {
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    } else if (MODE == 1) {
       asm volatile("v_pk_mul_f32 %0, %1, %2\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
       asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.x), "v"(a.x));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    } else if (MODE == 2) {
+      asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,1,0]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
+      asm volatile("v_fma_f32 %0, %1, %2, %1\n s_nop 0" : "=v"(lo) : "v"(x.x), "v"(a.y));
+      asm volatile("v_fma_f32 %0, %1, %2, %1\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    } else if (MODE == 3) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.y), "v"(a.x));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    } else if (MODE == 4) {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.x), "v"(a.x));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.x));
+    } else if (MODE == 5) {
+      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
+      asm volatile("v_add_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.x), "v"(a.y));
+      asm volatile("v_add_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    } else {
+      asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1]\n s_nop 2" : "=v"(d) : "v"(x), "v"(a));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(lo) : "v"(x.y), "v"(a.y));
+      asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
     }
-    asm volatile("v_mul_f32 %0, %1, %2\n s_nop 0" : "=v"(hi) : "v"(x.y), "v"(a.y));
+    if (__float_as_uint(d.x) != __float_as_uint(lo) && atomicCAS(&st->sample_taken, 0u, 1u) == 0u) {
+      st->sample[0] = x.x; st->sample[1] = x.y; st->sample[2] = a.x; st->sample[3] = a.y; st->sample[4] = d.x; st->sample[5] = lo;
+    }
     bad_lo += __float_as_uint(d.x) != __float_as_uint(lo);
     bad_hi += __float_as_uint(d.y) != __float_as_uint(hi);
     x.x = x.x * 0.999f + 1e-3f;  // operands change every pass (all normal numbers)
@@ -109,18 +141,30 @@ int main(int argc, char** argv) {
     std::vector<float> h((size_t)blocks * 256 * 2);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.5f + 1e-3f * (float)((i * 2654435761u) % 1999);
     hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 2; ++mode) {
+    const char* names[7] = {"mul op_sel:[0,1]", "mul", "fma op_sel:[0,1,0]", "mul op_sel:[1,0]", "mul op_sel_hi:[1,0]",
+                            "add op_sel:[0,1]", "mul op_sel:[1,1]"};
+    for (int mode = 0; mode < 7; ++mode) {
       hipMemset(st, 0, sizeof(Stats));
       for (int r = 0; r < R; ++r) {
-        if (mode == 0) hipLaunchKernelGGL(k_pk<0>, dim3(blocks), dim3(256), 0, 0, x, st, iters);
-        else hipLaunchKernelGGL(k_pk<1>, dim3(blocks), dim3(256), 0, 0, x, st, iters);
+        switch (mode) {
+          case 0: hipLaunchKernelGGL(k_pk<0>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          case 1: hipLaunchKernelGGL(k_pk<1>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          case 2: hipLaunchKernelGGL(k_pk<2>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          case 3: hipLaunchKernelGGL(k_pk<3>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          case 4: hipLaunchKernelGGL(k_pk<4>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          case 5: hipLaunchKernelGGL(k_pk<5>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+          default: hipLaunchKernelGGL(k_pk<6>, dim3(blocks), dim3(256), 0, 0, x, st, iters); break;
+        }
       }
       Stats s;
       hipMemcpy(&s, st, sizeof(s), hipMemcpyDeviceToHost);
-      printf("pk %-5s: %d launches, %llu waves (%llu changed HW_ID/XCC_ID while running); wrong results lo/hi per lane quarter:",
-             mode == 0 ? "asm" : "plain", R, s.waves, s.moved);
+      printf("v_pk_%-20s: %d launches, %llu waves (%llu changed HW_ID/XCC_ID while running); wrong lo/hi per lane quarter:",
+             names[mode], R, s.waves, s.moved);
       for (int q = 0; q < 4; ++q) printf(" [%llu %llu]", s.bad[q][0], s.bad[q][1]);
-      printf("; in moved waves %llu, in unmoved %llu\n", s.bad_in_moved, s.bad_in_unmoved);
+      if (s.sample_taken)
+        printf("; one wrong low product: x = (%g, %g) a = (%g, %g): packed %g, scalar %g", s.sample[0], s.sample[1],
+               s.sample[2], s.sample[3], s.sample[4], s.sample[5]);
+      printf("\n");
       fflush(stdout);
     }
   }
