@@ -8,7 +8,7 @@
 //   walk  : compiler-generated code of the attention walk's shape (row loads, fast sigmoid, 8-lane head sums, row times
 //           head factor, row store), launched again and again on the same inputs and compared with its first output
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast tools/lab/pk_micro.hip -o tools/lab/pk_micro
-//   tools/lab/pk_micro [launches per mode]
+//   tools/lab/pk_micro [launches per mode] [twostream]      (twostream: two co-resident kernels of ONE process instead)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -167,6 +167,29 @@ int main(int argc, char** argv) {
       printf("\n");
       fflush(stdout);
     }
+  }
+  if (argc > 2 && !strcmp(argv[2], "twostream")) {
+    // ---- ONE process, two streams: the failing form on one stream, another packed kernel on the other, co-resident
+    const int blocks = 2048, iters = 20000;
+    float* x;
+    Stats *st, *st2;
+    hipMalloc(&x, (size_t)blocks * 256 * 2 * 4); hipMalloc(&st, sizeof(Stats)); hipMalloc(&st2, sizeof(Stats));
+    std::vector<float> h((size_t)blocks * 256 * 2, 1.25f);
+    hipMemcpy(x, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemset(st, 0, sizeof(Stats)); hipMemset(st2, 0, sizeof(Stats));
+    hipStream_t s1, s2;
+    hipStreamCreateWithFlags(&s1, hipStreamNonBlocking); hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+    for (int r = 0; r < 4 * R; ++r) {
+      hipLaunchKernelGGL(k_pk<0>, dim3(blocks), dim3(256), 0, s1, x, st, iters);
+      hipLaunchKernelGGL(k_pk<6>, dim3(blocks), dim3(256), 0, s2, x, st2, iters);
+    }
+    hipDeviceSynchronize();
+    Stats s;
+    hipMemcpy(&s, st, sizeof(s), hipMemcpyDeviceToHost);
+    printf("two streams of ONE process (op_sel:[0,1] next to op_sel:[1,1], %d launches each, half the chip each): wrong lo/hi per lane quarter:", 4 * R);
+    for (int q = 0; q < 4; ++q) printf(" [%llu %llu]", s.bad[q][0], s.bad[q][1]);
+    printf("\n");
+    return 0;
   }
   {  // ---- the walk
     const int N = 8192, DEG = 16, E = N * DEG;
