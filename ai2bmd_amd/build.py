@@ -32,8 +32,9 @@ PER_FILE_FLAGS = {"md.hip": ["-ffp-contract=off"], "hydrogen.hip": ["-ffp-contra
 # runs kernels on the same GPU, `v_pk_mul_f32 d, x, a op_sel:[0,1]` (both halves times a.hi - what the compiler emits
 # for "row times one factor") returns a wrong LOW half in lanes 48..63 about 3e-6 of the time - the attention walk's `m`
 # rows came out with 16 zeroed channels and a fragment batch differed by 1e-2 eV/A from call to call.  One process per GPU
-# never shows it; a library must not depend on that.  Scalar fp32 VALU is the same arithmetic (bit-identical results)
-# and costs nothing here: the walks wait for memory and the products run on MFMA (Chignolin 450.4 -> 454.9 steps/s).
+# never shows it; a library must not depend on that.  Scalar fp32 VALU is the same IEEE arithmetic (the compiler's
+# contraction choices move the last ulp: smoke |dF| against fp64 1.18e-6 -> 1.22e-6) and costs nothing here: the walks
+# wait for memory and the products run on MFMA (Chignolin 450.4 -> 454.9 steps/s, alternating runs on one box).
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", *NO_PACKED_FP32, "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
 
