@@ -8,6 +8,33 @@
 #define VSN_XCD_REMAP 1
 #endif
 
+// Launch bounds of a node-walk kernel: WPN waves per node (single-protein sizes) or one wave per node in workgroups of
+// four (batches), plus an occupancy HINT per size class (amdgpu_waves_per_eu): BW / MW = the waves per SIMD the
+// one-wave-per-node / the WPN-waves-per-node instantiation is compiled for, 0 = the compiler's default.  Why: left alone
+// the scheduler aims at 8 waves per SIMD, i.e. <= 64 VGPRs, and gets there by issuing the row loads of an edge ONE AFTER
+// THE OTHER into the same registers (k_bwd_vecmsg_S: 8 x {global_load_dwordx4; s_waitcnt vmcnt(0); 4 fmac}); told that
+// 4 waves per SIMD are enough it keeps the loads of an edge in flight together (81 VGPRs, 514 -> 425 us on the
+// 4096-fragment batch).  A request below the minimum the workgroup size implies is ignored by the compiler, which is how
+// "0" is spelled here: (1, 8).  Lab builds: -DVSN_LAB_BATCH_WPE=n / -DVSN_LAB_MD_WPE=n override every kernel's hint.
+#if defined(VSN_LAB_BATCH_WPE) || defined(VSN_LAB_MD_WPE)
+#ifndef VSN_LAB_BATCH_WPE
+#define VSN_LAB_BATCH_WPE 0
+#endif
+#ifndef VSN_LAB_MD_WPE
+#define VSN_LAB_MD_WPE 0
+#endif
+#define VSN_WPE_B(BW) (VSN_LAB_BATCH_WPE ? VSN_LAB_BATCH_WPE : (BW))
+#define VSN_WPE_M(MW) (VSN_LAB_MD_WPE ? VSN_LAB_MD_WPE : (MW))
+#else
+#define VSN_WPE_B(BW) (BW)
+#define VSN_WPE_M(MW) (MW)
+#endif
+#define VSN_WALK_BOUNDS_H(WPN, BW, MW)                                                                   \
+  __launch_bounds__(64 * ((WPN) == 1 ? 4 : (WPN)))                                                       \
+      __attribute__((amdgpu_waves_per_eu((WPN) == 1 ? (VSN_WPE_B(BW) ? VSN_WPE_B(BW) : 1) : (VSN_WPE_M(MW) ? 2 : 1), \
+                                         (WPN) == 1 ? (VSN_WPE_B(BW) ? VSN_WPE_B(BW) : 8) : (VSN_WPE_M(MW) ? VSN_WPE_M(MW) : 8))))
+#define VSN_WALK_BOUNDS(WPN) VSN_WALK_BOUNDS_H(WPN, 0, 0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

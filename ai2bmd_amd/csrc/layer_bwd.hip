@@ -277,7 +277,7 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
 }
 
 template <int V, int S, int WPN, bool GEN, int CS = 1>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_T(
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_edge_update_T(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const floa
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_edge_update_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_edge_update_S(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_vp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -410,7 +410,7 @@ __device__ __forceinline__ void bwd_vecmsg_T_body(const Dims& D, const float* __
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_T(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_vecmsg_T(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ vh, const float* __restrict__ tpre,
     float* __restrict__ g_t, float* __restrict__ g_geo) {
   bwd_vecmsg_T_body<V, S, WPN, GEN>(D, g_vec, vh, tpre, g_t, g_geo, (int)blockIdx.x, (int)gridDim.x);
@@ -461,7 +461,7 @@ __device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_vecmsg_S(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, (int)blockIdx.x, (int)gridDim.x);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_vecmsg_S(
 // messages.  They are independent of each other (own outputs, own g_geo slots) and latency-bound at single-protein
 // sizes: side by side they take as long as the longest, and the step has two launches less per layer.
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_side(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_side(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo, const float* __restrict__ g_vec,
     const float* __restrict__ tpre, float* __restrict__ g_vh) {
@@ -621,7 +621,7 @@ __device__ __forceinline__ void bwd_attn_T_body(const Dims& D, const float* __re
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_T(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_attn_T(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
     float* __restrict__ g_geo, Parts mp, Parts ap) {
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN), ((WPN > 1 && V <= 4 && !
   }
 }
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf2(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_hf2(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_A,
     float* __restrict__ g_m, float* __restrict__ g_pe, float* __restrict__ g_qkv, float* __restrict__ sat_tmp,
     float* __restrict__ g_geo, Parts mp, Parts ap, const float* __restrict__ vp, const float* __restrict__ g_f,
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_hf2(
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_attn_S(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_m,
     const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_S(
 // (fragment batches: the rest of the target-side attention adjoint is the prologue of the fused g_f product,
 //  fused.hip::k_bwd_gf_fused, which leaves g_sat in sat_tmp; a per-node sum cannot live in a per-edge-panel kernel)
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_attn_Q(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_attn_Q(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ sat_tmp,
     float* __restrict__ g_qkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256) void k_bwd_node_norm(Dims D, const float* __re
 // of layer l-1 (k_bwd_node_norm + k_bwd_node_update in one pass: both are node-local, g_x / g_vec of the
 // node stay in registers between the two)
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(WPN == 1 ? 256 : 64 * WPN) void k_bwd_norm_update(Dims D, const float* __restrict__ g_xh, int ldg,
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_norm_update(Dims D, const float* __restrict__ g_xh, int ldg,
                                                          const float* __restrict__ g_vh,
                                                          const float* __restrict__ xn,
                                                          const float* __restrict__ rstd,
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(WPN == 1 ? 256 : 64 * WPN) void k_bwd_norm_update(D
 // g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
 // g_xh != nullptr: the LayerNorm adjoint of layer 0 (what k_bwd_node_norm adds to g_x) rides in the node epilogue
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_embed_edge(
     Dims D, const float* __restrict__ x, const float* __restrict__ pp, const float* __restrict__ g_f,
     float* __restrict__ g_pp, float* __restrict__ g_x, const float* __restrict__ g_xh,
     const float* __restrict__ xn, const float* __restrict__ rstd, const float* __restrict__ gamma) {
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_edge(
 // ---- adjoint of NeighborEmbedding's aggregation (utils.py:296-317) -------------------
 // g_Wn = g_n_i emb2[z_j] (non-loop) ; g_phi = g_Wn C ; g_C += sum_c g_Wn phi
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_bwd_embed_node(
+__global__ VSN_WALK_BOUNDS(WPN) void k_bwd_embed_node(
     Dims D, const float* __restrict__ emb2, const float* __restrict__ pp, const float* __restrict__ g_n,
     float* __restrict__ g_pp, float* __restrict__ g_geo) {
   const int H = D.H;

@@ -152,7 +152,7 @@ __device__ __forceinline__ void node_layernorm_store(const NextNorm& nn, int i, 
 // ---- embeddings -------------------------------------------------------------
 // cat[i] = [ emb1[z_i] | sum_{j->i, j!=i} emb2[z_j] * phi_e * C_e ]   (utils.py:296-317)
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_node(Dims D, const float* __restrict__ emb1,
+__global__ VSN_WALK_BOUNDS(WPN) void k_embed_node(Dims D, const float* __restrict__ emb1,
                                                                           const float* __restrict__ emb2,
                                                                           const float* __restrict__ pp,
                                                                           float* __restrict__ cat) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_node(Dims D
 // nn.xn != nullptr: also layer 0's LayerNorm of x and its VecLayerNorm("none") of vec == 0 (vh = 0), i.e. what
 // k_node_norm would do in a launch of its own
 template <int V, int S, int WPN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_embed_edge(Dims D, const float* __restrict__ x,
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_embed_edge(Dims D, const float* __restrict__ x,
                                                                           const float* __restrict__ pp,
                                                                           float* __restrict__ f,
                                                                           float* __restrict__ vec,
@@ -329,7 +329,7 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
   }
 }
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D, const float* __restrict__ qkv,
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_edge_attn(Dims D, const float* __restrict__ qkv,
                                                                          const float* __restrict__ pe,
                                                                          float* __restrict__ m,
                                                                          float* __restrict__ A) {
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn(Dims D,
 // V_i[s] = sum_e vh_j[s]*s1_e + d_e[s]*s2_e ; dx = (sum_s vec1 vec2) o2 + o3 ;
 // dvec = vec3 o1 + V ; x += dx ; vec += dvec    (visnet_block.py:284-288,271-274,129-137)
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_node_update(Dims D, const float* __restrict__ tpre,
+__global__ VSN_WALK_BOUNDS(WPN) void k_node_update(Dims D, const float* __restrict__ tpre,
                                                                            const float* __restrict__ vh,
                                                                            const float* __restrict__ vp,
                                                                            const float* __restrict__ o,
@@ -529,7 +529,7 @@ __device__ __forceinline__ void edge_update_body(const Dims& D, const float* __r
   }
 }
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims D, const float* __restrict__ vp,
+__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_edge_update(Dims D, const float* __restrict__ vp,
                                                                            const float* __restrict__ pe,
                                                                            float* __restrict__ f) {
   edge_update_body<V, S, WPN, GEN>(D, vp, pe, f, (int)blockIdx.x, (int)gridDim.x);
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_update(Dims 
 // blocks [0, G) do the attention, blocks [G, 2G) the edge update.  On a single protein both are latency-bound,
 // so one launch runs them side by side without the ~15 us event latency a second stream would cost.
 template <int V, int S, int WPN, bool GEN>
-__global__ __launch_bounds__(64 * (WPN == 1 ? 4 : WPN)) void k_edge_attn_update(Dims D, const float* __restrict__ qkv,
+__global__ VSN_WALK_BOUNDS(WPN) void k_edge_attn_update(Dims D, const float* __restrict__ qkv,
                                                                                 const float* __restrict__ pe,
                                                                                 float* __restrict__ m,
                                                                                 float* __restrict__ A,
