@@ -62,6 +62,24 @@ __device__ __forceinline__ float half_sum(float v) {
   return v;
 }
 
+// the (target, source) node ids of the 16 panel rows a wave gathers, fetched ONCE per panel with one coalesced load each
+// (lane & 15 = row within the wave's 16) instead of per row inside the gather loop, where every row's loads waited for
+// them: one dependent round trip per row instead of two.  Rows past the live edge count read the last live edge, as the
+// loop did.
+struct PanelIds {
+  int tgt, src;
+};
+__device__ __forceinline__ PanelIds panel_ids(const Dims& D, const int e0, const int Meff, const int tw, const int lane) {
+  int e = e0 + tw * 16 + (lane & 15);
+  e = e < Meff ? e : Meff - 1;
+  return PanelIds{D.tgt[e], D.src[e]};
+}
+// row 2 t + hw of those 16 (t wave-uniform, hw = the lane's half-wave)
+__device__ __forceinline__ int panel_id_at(const int ids, const int t, const int hw) {
+  const int a = __builtin_amdgcn_readlane(ids, 2 * t), b = __builtin_amdgcn_readlane(ids, 2 * t + 1);
+  return hw ? b : a;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // g_m[E,H] = g_t[E,2H] . Ws      with g_t produced on the fly (adjoint of the vector messages, target side;
 // same arithmetic as k_bwd_vecmsg_T):
@@ -75,7 +93,7 @@ template <bool GEN, int U = 2>
 __device__ __forceinline__ void gm_gather(const Dims& D, const float* __restrict__ g_vec, const float* __restrict__ vh,
                                           const float* __restrict__ tpre, float* __restrict__ g_geo,
                                           float* __restrict__ smem, const int e0, const int Meff, const int h,
-                                          const int tw, const int lane, const int abl) {
+                                          const int tw, const int lane, const int abl, const PanelIds ids) {
   const int l5 = lane & 31, hw = lane >> 5;
   const int act = GEN ? D.act : VSN_ACT_SILU;
   const int c0 = 128 * h + 4 * l5;
@@ -88,7 +106,7 @@ __device__ __forceinline__ void gm_gather(const Dims& D, const float* __restrict
     const int r = tw * 16 + 2 * t + hw;  // panel row of this half-wave
     const bool valid = e0 + r < Meff;
     const int e = valid ? e0 + r : Meff - 1;
-    const int i = D.tgt[e], j = D.src[e];
+    const int i = panel_id_at(ids.tgt, t, hw), j = panel_id_at(ids.src, t, hw);
     const float* __restrict__ tp = tpre + (size_t)e * 512 + c0;
     const f32x4 t1 = *reinterpret_cast<const f32x4*>(tp);
     const f32x4 t2 = *reinterpret_cast<const f32x4*>(tp + 256);
@@ -157,10 +175,11 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gm_fused(Dims D, const float* __
   typename G::Ring ring;
   G::prefetch(ring, Bp, 512, 0, wave, lane);
   const int abl = VSN_FUSED_ABL();
+  const PanelIds ids = panel_ids(D, e0, Meff, wave, lane);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();  // every wave is done reading slice 0
-    gm_gather<GEN>(D, g_vec, vh, tpre, g_geo, smem, e0, Meff, h, wave, lane, abl);
+    gm_gather<GEN>(D, g_vec, vh, tpre, g_geo, smem, e0, Meff, h, wave, lane, abl, ids);
     __syncthreads();
     G::pin(ring);
     if (!(abl & 2)) G::slice(acc, ring, smem, Bp, 512, h, wave, lane);
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gm_fused_tp(Dims D, const float*
     G::zero(acc);
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
-      gm_gather<GEN, 1>(D, g_vec, vh, tpre, g_geo, smem, e0, Meff, h, tw, lane, abl);
+      gm_gather<GEN, 1>(D, g_vec, vh, tpre, g_geo, smem, e0, Meff, h, tw, lane, abl, panel_ids(D, e0, Meff, tw, lane));
       // the B ring is (re)filled per slice, AFTER the gather: 32 registers the gather then has for its rows (the
       // read-ahead at the tail of the previous slice is dropped; the barrier wait covers the latency of this one)
       G::prefetch(ring, Bp, 512, h, tw, lane);
@@ -255,7 +274,7 @@ __device__ __forceinline__ void gf_gather(const Dims& D, const float* __restrict
                                           const float* __restrict__ g_A, float* __restrict__ g_m,
                                           float* __restrict__ sat_tmp, float* __restrict__ g_geo,
                                           float* __restrict__ smem, const int e0, const int Meff, const int h,
-                                          const int tw, const int lane, const int abl) {
+                                          const int tw, const int lane, const int abl, const PanelIds ids) {
   const int l5 = lane & 31, hw = lane >> 5;
   const int act = GEN ? D.act : VSN_ACT_SILU, aact = GEN ? D.attn_act : VSN_ACT_SILU;
   const int nh = D.nh;
@@ -269,7 +288,7 @@ __device__ __forceinline__ void gf_gather(const Dims& D, const float* __restrict
     const int r = tw * 16 + 2 * t + hw;
     const bool valid = e0 + r < Meff;
     const int e = valid ? e0 + r : Meff - 1;
-    const int i = D.tgt[e], j = D.src[e];
+    const int i = panel_id_at(ids.tgt, t, hw), j = panel_id_at(ids.src, t, hw);
     const float C = D.geo[(size_t)e * 8 + 1];
     const float gC_old = l5 == 0 ? g_geo[(size_t)e * VSN_GEO_W + 8] : 0.f;
     if (i != i_prev) {
@@ -339,10 +358,11 @@ __global__ __launch_bounds__(256, 2) void k_bwd_gf_fused(Dims D, const float* __
   typename G::Ring ring;
   G::prefetch(ring, Bp, K, 0, wave, lane);
   const int abl = VSN_FUSED_ABL();
+  const PanelIds ids = panel_ids(D, e0, Meff, wave, lane);
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     if (h) __syncthreads();
-    gf_gather<GEN>(D, qkv, pe, g_A, g_m, sat_tmp, g_geo, smem, e0, Meff, h, wave, lane, abl);
+    gf_gather<GEN>(D, qkv, pe, g_A, g_m, sat_tmp, g_geo, smem, e0, Meff, h, wave, lane, abl, ids);
     __syncthreads();
     G::pin(ring);
     if (!(abl & 2)) G::slice(acc, ring, smem, Bp, K, h, wave, lane);
@@ -394,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void k_bwd_gf_fused_tp(Dims D, const float*
     const int nsl = K > 512 ? 3 : 2;
 #pragma unroll 1
     for (int h = 0; h < nsl; ++h) {
-      if (h < 2) gf_gather<GEN, 1>(D, qkv, pe, g_A, g_m, sat_tmp, g_geo, smem, e0, Meff, h, tw, lane, abl);
+      if (h < 2) gf_gather<GEN, 1>(D, qkv, pe, g_A, g_m, sat_tmp, g_geo, smem, e0, Meff, h, tw, lane, abl, panel_ids(D, e0, Meff, tw, lane));
       else panel_load_dma<64, 4>(smem, g_pe, 768, e0, Meff, 512, tw, lane);  // (drained by the barrier)
       G::prefetch(ring, Bp, K, h, tw, lane);
       __syncthreads();
