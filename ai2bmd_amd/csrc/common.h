@@ -15,7 +15,8 @@
 // THE OTHER into the same registers (k_bwd_vecmsg_S: 8 x {global_load_dwordx4; s_waitcnt vmcnt(0); 4 fmac}); told that
 // 4 waves per SIMD are enough it keeps the loads of an edge in flight together (81 VGPRs, 514 -> 425 us on the
 // 4096-fragment batch).  A request below the minimum the workgroup size implies is ignored by the compiler, which is how
-// "0" is spelled here: (1, 8).  Lab builds: -DVSN_LAB_BATCH_WPE=n / -DVSN_LAB_MD_WPE=n override every kernel's hint.
+// "0" is spelled here: (1, 8).  The hinted kernels pass BW = (V <= 4 ? 4 : 0): hidden sizes above 256 need more than the
+// 128 registers of that budget per wave and keep the default.  Lab builds: -DVSN_LAB_BATCH_WPE=n / -DVSN_LAB_MD_WPE=n override every kernel's hint.
 #if defined(VSN_LAB_BATCH_WPE) || defined(VSN_LAB_MD_WPE)
 #ifndef VSN_LAB_BATCH_WPE
 #define VSN_LAB_BATCH_WPE 0

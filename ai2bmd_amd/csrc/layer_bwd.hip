@@ -277,7 +277,7 @@ __device__ __forceinline__ void bwd_edge_update_T_body(const Dims& D, const floa
 }
 
 template <int V, int S, int WPN, bool GEN, int CS = 1>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_edge_update_T(
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_bwd_edge_update_T(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_pe, float* __restrict__ g_vp, float* __restrict__ g_geo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,7 +340,7 @@ __device__ __forceinline__ void bwd_edge_update_S_body(const Dims& D, const floa
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_edge_update_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_bwd_edge_update_S(
     Dims D, const float* __restrict__ vp, const float* __restrict__ pe, const float* __restrict__ g_f,
     float* __restrict__ g_vp) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -461,7 +461,7 @@ __device__ __forceinline__ void bwd_vecmsg_S_body(const Dims& D, const float* __
 }
 
 template <int V, int S, int WPN, bool GEN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_vecmsg_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_bwd_vecmsg_S(
     Dims D, const float* __restrict__ g_vec, const float* __restrict__ tpre, float* __restrict__ g_vh) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   bwd_vecmsg_S_body<V, S, WPN, GEN>(D, g_vec, tpre, g_vh, smem, (int)blockIdx.x, (int)gridDim.x);
@@ -701,7 +701,7 @@ __global__ VSN_WALK_BOUNDS(WPN) void k_bwd_hf2(
 
 // ---- source side: g_k_j = sum g_sat q_i dk ; g_v_j = sum gm dv a ---------------------
 template <int V, int S, int WPN, bool GEN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_attn_S(
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_bwd_attn_S(
     Dims D, const float* __restrict__ qkv, const float* __restrict__ pe, const float* __restrict__ g_m,
     const float* __restrict__ sat_tmp, float* __restrict__ g_qkv) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1026,7 +1026,7 @@ __global__ VSN_WALK_BOUNDS(WPN) void k_bwd_norm_update(Dims D, const float* __re
 // g_psi_e = g_f_e (x_i + x_j) ; g_x_i += sum_{in} g_f psi + sum_{out} g_f psi
 // g_xh != nullptr: the LayerNorm adjoint of layer 0 (what k_bwd_node_norm adds to g_x) rides in the node epilogue
 template <int V, int S, int WPN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_bwd_embed_edge(
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_bwd_embed_edge(
     Dims D, const float* __restrict__ x, const float* __restrict__ pp, const float* __restrict__ g_f,
     float* __restrict__ g_pp, float* __restrict__ g_x, const float* __restrict__ g_xh,
     const float* __restrict__ xn, const float* __restrict__ rstd, const float* __restrict__ gamma) {

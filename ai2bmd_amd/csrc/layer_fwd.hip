@@ -188,7 +188,7 @@ __global__ VSN_WALK_BOUNDS(WPN) void k_embed_node(Dims D, const float* __restric
 // nn.xn != nullptr: also layer 0's LayerNorm of x and its VecLayerNorm("none") of vec == 0 (vh = 0), i.e. what
 // k_node_norm would do in a launch of its own
 template <int V, int S, int WPN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_embed_edge(Dims D, const float* __restrict__ x,
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_embed_edge(Dims D, const float* __restrict__ x,
                                                                           const float* __restrict__ pp,
                                                                           float* __restrict__ f,
                                                                           float* __restrict__ vec,
@@ -329,7 +329,7 @@ __device__ __forceinline__ void edge_attn_body(const Dims& D, const float* __res
   }
 }
 template <int V, int S, int WPN, bool GEN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_edge_attn(Dims D, const float* __restrict__ qkv,
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_edge_attn(Dims D, const float* __restrict__ qkv,
                                                                          const float* __restrict__ pe,
                                                                          float* __restrict__ m,
                                                                          float* __restrict__ A) {
@@ -529,7 +529,7 @@ __device__ __forceinline__ void edge_update_body(const Dims& D, const float* __r
   }
 }
 template <int V, int S, int WPN, bool GEN>
-__global__ VSN_WALK_BOUNDS_H(WPN, 4, 0) void k_edge_update(Dims D, const float* __restrict__ vp,
+__global__ VSN_WALK_BOUNDS_H(WPN, (V <= 4 ? 4 : 0), 0) void k_edge_update(Dims D, const float* __restrict__ vp,
                                                                            const float* __restrict__ pe,
                                                                            float* __restrict__ f) {
   edge_update_body<V, S, WPN, GEN>(D, vp, pe, f, (int)blockIdx.x, (int)gridDim.x);
